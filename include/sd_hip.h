@@ -1,0 +1,203 @@
+/*
+ * sd_hip.h — C ABI of libsd_hip.so, the MI355X (gfx950) embedding hot path.
+ *
+ * The reference (hzane/speech-diarization) has no native code and no FFI: its
+ * boundary for this path is a set of Python callables that bottom out in
+ * third-party libraries.  Each entry point below replaces the arithmetic behind
+ * one of those call sites; the Python modules of the same names as the
+ * reference's (speech_encode / ecapa_annote / ...) bind them with ctypes.
+ *
+ *   sd_fbank_*            replaces  torchaudio MelSpectrogram + log + mean-norm
+ *                                   [REF speech_encode.py:17-36]  (fbank_batch)
+ *                         and       speechbrain Fbank + InputNormalization inside
+ *                                   encode_batch [REF speech_encode.py:77]
+ *   sd_ecapa_*            replaces  speechbrain ECAPA_TDNN forward inside
+ *                                   EncoderClassifier.encode_batch
+ *                                   [REF speech_encode.py:73-78] [REF ecapa_annote.py:22]
+ *   sd_conv1d_cl_f32 ...  the layer operators sd_ecapa_forward is built from
+ *   sd_cosine_affinity_f32 replaces sklearn cosine_similarity(X)
+ *                                   [REF anti_stick_diarize.py:177] [REF diar_diag.py:215,219,278,355]
+ *   sd_l2norm_rows_f32    replaces  X / (||X|| + 1e-8) [REF anti_stick_diarize.py:176,430]
+ *   sd_adjacent_cosine_f32 replaces the einsum pair cosine [REF anti_stick_diarize.py:102-104]
+ *   sd_sim_argmax_f32     replaces  argmax(W @ C.T) [REF anti_stick_diarize.py:433-434]
+ *
+ * Conventions: every pointer named *_dev / documented "device" is a HIP device
+ * pointer; all functions are asynchronous on `stream`, never allocate and never
+ * synchronise in the launch path (plan/weights creation excepted).  Return value
+ * 0 = ok, negative = error (message via sd_last_error(), thread-local).
+ */
+#ifndef SD_HIP_H
+#define SD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sd_stream_t; /* hipStream_t */
+
+#define SD_OK 0
+#define SD_ERR_ARG (-1)
+#define SD_ERR_UNSUPPORTED (-2)
+#define SD_ERR_WORKSPACE (-3)
+#define SD_ERR_HIP (-4)
+
+#define SD_ABI_VERSION 1
+
+int sd_abi_version(void);
+const char* sd_last_error(void);
+/* number of HIP devices visible, or negative error */
+int sd_device_count(void);
+
+/* ------------------------------------------------------------------ fbank */
+
+/* pad_mode */
+#define SD_PAD_ZERO 0    /* speechbrain STFT: center=True, pad_mode="constant" */
+#define SD_PAD_REFLECT 1 /* torchaudio Spectrogram: center=True, pad_mode="reflect" */
+/* log_mode */
+#define SD_LOG_LN_EPS 0   /* ln(x + eps)                           [REF speech_encode.py:32] */
+#define SD_LOG_DB_TOPDB 1 /* 10*log10(max(x, eps)), floor at utterance max - top_db */
+
+typedef struct sd_fbank_plan sd_fbank_plan;
+
+/* window: host [n_fft] (must satisfy w[k] == w[n_fft-k], true for periodic
+ * Hann/Hamming); mel_fb: host [n_fft/2+1][n_mels] row-major, at most 2 non-zero
+ * filters per frequency bin (triangular banks).  Only n_fft=400, hop=160 (25 ms
+ * / 10 ms at 16 kHz, [REF speech_encode.py:14-15]) is implemented.  Allocates
+ * the device-side basis / filter tables. */
+sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, int hop,
+                                    const float* mel_fb, int n_mels,
+                                    int pad_mode, int log_mode, float log_eps, float top_db);
+void sd_fbank_plan_destroy(sd_fbank_plan* plan);
+
+/* frames per utterance of n samples: 1 + n / hop (center=True) */
+int sd_fbank_num_frames(const sd_fbank_plan* plan, int n);
+size_t sd_fbank_workspace_bytes(const sd_fbank_plan* plan, int B, int n);
+
+/* wav_dev: device f32 [B][n]; out_dev: device f32 [B][T][n_mels]
+ * (ld_out = row stride of out in floats, >= n_mels);
+ * mean_norm != 0 subtracts each utterance's per-bin mean over T. */
+int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int B, int n,
+                 int mean_norm, float* out_dev, int ld_out,
+                 void* ws_dev, size_t ws_bytes, sd_stream_t stream);
+
+/* --------------------------------------------------------- layer operators */
+
+#define SD_ACT_NONE 0
+#define SD_ACT_RELU 1
+#define SD_ACT_TANH 2
+#define SD_ACT_SIGMOID 3
+
+#define SD_DT_F32 0
+#define SD_DT_F16 1
+
+/* Channel-last 1-D convolution as an implicit GEMM on the matrix cores:
+ *   y[m, n] = act2( affine( act( bias[n] + sum_{j<taps} sum_{c<cin}
+ *                 x[rowmap(m, j), a_col0 + c] * w[n][j][c] ) ) )
+ * with m = b*T + t and rowmap reflecting t + (j - taps/2)*dil into [0, T)
+ * ("same" padding, reflect mode — speechbrain Conv1d).  x: [M][lda] f32,
+ * w: packed [cout][taps][cin_pad] (cin_pad = cin rounded up to 32, zero filled),
+ * y: [M][ldo] written at column o_col0.  Optional "tee": for output columns in
+ * [tee_lo, tee_hi) also store y (+ tee_add[m, ta_col0 + n - tee_lo]) to
+ * tee[m, n - tee_lo]; this carries the Res2Net chain's  c_{j+1} + y_j  add. */
+typedef struct {
+  const float* x; int lda; int a_col0;
+  const void* w;  int w_dtype;
+  float* y; int ldo; int o_col0;
+  int M; int T;
+  int cin; int cin_pad; int cout; int taps; int dil;
+  const float* bias; int bias_per_seg; /* bias[n], or bias[(m / T) * cout + n] */
+  int act;
+  const float* scale; const float* shift; /* per-channel affine after act (eval BatchNorm), may be NULL */
+  int act2;
+  float* tee; int ldt; int tee_lo; int tee_hi;
+  const float* tee_add; int ld_ta; int ta_col0;
+} sd_conv_args;
+
+int sd_conv1d_cl_f32(const sd_conv_args* args, sd_stream_t stream);
+
+/* mean over the T rows of every segment: x [B*T][ld] cols [col0, col0+C) -> mean [B][C] */
+int sd_seg_mean_f32(const float* x, int ld, int col0, int B, int T, int C,
+                    float* mean, sd_stream_t stream);
+/* mean and sqrt(clamp(mean((x-mean)^2), eps)) over T -> stats [B][2*C] = [mean | std] */
+int sd_seg_mean_std_f32(const float* x, int ld, int col0, int B, int T, int C,
+                        float eps, float* stats, sd_stream_t stream);
+/* y[m, y_col0 + c] = x[m, c] * gate[m / T, c] + res[m, r_col0 + c]   (SE scale + shortcut) */
+int sd_se_scale_residual_f32(const float* x, int ldx, const float* gate,
+                             const float* res, int ldr, int r_col0,
+                             float* y, int ldy, int y_col0,
+                             int B, int T, int C, sd_stream_t stream);
+/* attentive statistics pooling: a = softmax_T(logit); mu = sum a*h;
+ * sd = sqrt(clamp(sum a*(h-mu)^2, eps));  out [B][2*C] = [mu | sd] */
+int sd_asp_pool_f32(const float* logit, int ldl, const float* h, int ldh,
+                    int B, int T, int C, float eps, float* out, sd_stream_t stream);
+
+/* ------------------------------------------------------------ ECAPA-TDNN */
+
+typedef struct {
+  const void* w;      /* packed [cout][taps][cin_pad] */
+  const float* bias;  /* [cout] or NULL */
+  const float* scale; /* [cout] eval-BN scale or NULL */
+  const float* shift; /* [cout] eval-BN shift or NULL */
+  int cin, cin_pad, cout, taps, dil;
+} sd_layer;
+
+#define SD_MAX_RES2 15
+#define SD_MAX_BLOCKS 8
+
+typedef struct {
+  sd_layer tdnn1;
+  sd_layer res2[SD_MAX_RES2]; /* scale-1 used */
+  sd_layer tdnn2;
+  sd_layer se1, se2;
+} sd_se_res2_block;
+
+/* speechbrain ECAPA_TDNN geometry (Appendix A.3 of SURVEY.md) */
+typedef struct {
+  int w_dtype;        /* SD_DT_F32 */
+  int n_mels;         /* 80 */
+  int channels;       /* C = 1024: width of blocks 0..n_blocks */
+  int n_blocks;       /* 3 SE-Res2Net blocks */
+  int res2_scale;     /* 8 */
+  int mfa_channels;   /* n_blocks * C = 3072 */
+  int att_channels;   /* 128 */
+  int emb_dim;        /* 192 */
+  float asp_eps;      /* 1e-12 */
+  sd_layer block0;
+  sd_se_res2_block blocks[SD_MAX_BLOCKS];
+  sd_layer mfa;
+  sd_layer asp_tdnn_h; /* attention TDNN, columns acting on h      (mfa -> att) */
+  sd_layer asp_tdnn_g; /* attention TDNN, columns acting on [mu|sd] (2*mfa -> att), bias here */
+  sd_layer asp_conv;   /* att -> mfa */
+  sd_layer fc;         /* 2*mfa -> emb, asp_bn folded in */
+} sd_ecapa_weights;
+
+size_t sd_ecapa_workspace_bytes(const sd_ecapa_weights* w, int B, int T);
+
+/* feats: device f32 [B][T][n_mels] (mean-normalised fbank); emb: device f32 [B][emb_dim] */
+int sd_ecapa_forward_f32(const sd_ecapa_weights* w, const float* feats, int B, int T,
+                         float* emb, void* ws_dev, size_t ws_bytes, sd_stream_t stream);
+
+/* ------------------------------------------------------ cosine / affinity */
+
+/* xn[i] = x[i] / (||x[i]|| + eps_add), rows with ||x|| == 0 divided by 1 when
+ * sklearn_zero_guard != 0 (sklearn.preprocessing.normalize semantics). */
+int sd_l2norm_rows_f32(const float* x, int ldx, int N, int D, float eps_add, int sklearn_zero_guard,
+                       float* xn, int ldo, sd_stream_t stream); /* columns [D, ldo) of xn are zero filled */
+/* out [N][N] = normalize(X) @ normalize(X).T, sklearn cosine_similarity semantics.
+ * ws_dev: N*D_pad floats (sd_cosine_workspace_bytes). */
+size_t sd_cosine_workspace_bytes(int N, int D);
+int sd_cosine_affinity_f32(const float* x, int N, int D, float* out, int ldo,
+                           void* ws_dev, size_t ws_bytes, sd_stream_t stream);
+/* sims[i] = <x[i], x[i+1]> / (||x[i]|| * ||x[i+1]|| + eps), i < N-1 */
+int sd_adjacent_cosine_f32(const float* x, int ldx, int N, int D, float eps, float* sims, sd_stream_t stream);
+/* best[i] = argmax_k <w[i], c[k]> (first max wins, numpy argmax), score[i] = max */
+int sd_sim_argmax_f32(const float* w, int ldw, int N, int D, const float* c, int ldc, int K,
+                      int32_t* best, float* score, sd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_HIP_H */

@@ -1,0 +1,141 @@
+"""ctypes binding of libsd_hip.so (C ABI: include/sd_hip.h).
+
+The HIP library is the product path.  There is no CPU fallback: if the shared
+object is missing, or exports fewer symbols than the header declares, loading
+raises instead of degrading silently.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libsd_hip.so"
+
+SD_OK = 0
+SD_PAD_ZERO, SD_PAD_REFLECT = 0, 1
+SD_LOG_LN_EPS, SD_LOG_DB_TOPDB = 0, 1
+SD_ACT_NONE, SD_ACT_RELU, SD_ACT_TANH, SD_ACT_SIGMOID = 0, 1, 2, 3
+SD_DT_F32, SD_DT_F16 = 0, 1
+SD_MAX_RES2 = 15
+SD_MAX_BLOCKS = 8
+SD_ABI_VERSION = 1
+
+
+class SdError(RuntimeError):
+    """A libsd_hip.so entry point returned a non-zero status."""
+
+
+class sd_conv_args(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("lda", C.c_int), ("a_col0", C.c_int),
+        ("w", C.c_void_p), ("w_dtype", C.c_int),
+        ("y", C.c_void_p), ("ldo", C.c_int), ("o_col0", C.c_int),
+        ("M", C.c_int), ("T", C.c_int),
+        ("cin", C.c_int), ("cin_pad", C.c_int), ("cout", C.c_int), ("taps", C.c_int), ("dil", C.c_int),
+        ("bias", C.c_void_p), ("bias_per_seg", C.c_int),
+        ("act", C.c_int),
+        ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("act2", C.c_int),
+        ("tee", C.c_void_p), ("ldt", C.c_int), ("tee_lo", C.c_int), ("tee_hi", C.c_int),
+        ("tee_add", C.c_void_p), ("ld_ta", C.c_int), ("ta_col0", C.c_int),
+    ]
+
+
+class sd_layer(C.Structure):
+    _fields_ = [
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("cin", C.c_int), ("cin_pad", C.c_int), ("cout", C.c_int), ("taps", C.c_int), ("dil", C.c_int),
+    ]
+
+
+class sd_se_res2_block(C.Structure):
+    _fields_ = [
+        ("tdnn1", sd_layer),
+        ("res2", sd_layer * SD_MAX_RES2),
+        ("tdnn2", sd_layer),
+        ("se1", sd_layer), ("se2", sd_layer),
+    ]
+
+
+class sd_ecapa_weights(C.Structure):
+    _fields_ = [
+        ("w_dtype", C.c_int), ("n_mels", C.c_int), ("channels", C.c_int), ("n_blocks", C.c_int),
+        ("res2_scale", C.c_int), ("mfa_channels", C.c_int), ("att_channels", C.c_int), ("emb_dim", C.c_int),
+        ("asp_eps", C.c_float),
+        ("block0", sd_layer),
+        ("blocks", sd_se_res2_block * SD_MAX_BLOCKS),
+        ("mfa", sd_layer), ("asp_tdnn_h", sd_layer), ("asp_tdnn_g", sd_layer), ("asp_conv", sd_layer), ("fc", sd_layer),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_Z = C.c_size_t
+
+# symbol -> (restype, argtypes); must list every function sd_hip.h declares
+PROTOTYPES = {
+    "sd_abi_version": (_I, []),
+    "sd_last_error": (C.c_char_p, []),
+    "sd_device_count": (_I, []),
+    "sd_fbank_plan_create": (_P, [_P, _I, _I, _P, _I, _I, _I, _F, _F]),
+    "sd_fbank_plan_destroy": (None, [_P]),
+    "sd_fbank_num_frames": (_I, [_P, _I]),
+    "sd_fbank_workspace_bytes": (_Z, [_P, _I, _I]),
+    "sd_fbank_f32": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    "sd_conv1d_cl_f32": (_I, [C.POINTER(sd_conv_args), _P]),
+    "sd_seg_mean_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "sd_seg_mean_std_f32": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "sd_se_scale_residual_f32": (_I, [_P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "sd_asp_pool_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P]),
+    "sd_ecapa_workspace_bytes": (_Z, [C.POINTER(sd_ecapa_weights), _I, _I]),
+    "sd_ecapa_forward_f32": (_I, [C.POINTER(sd_ecapa_weights), _P, _I, _I, _P, _P, _Z, _P]),
+    "sd_l2norm_rows_f32": (_I, [_P, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "sd_cosine_workspace_bytes": (_Z, [_I, _I]),
+    "sd_cosine_affinity_f32": (_I, [_P, _I, _I, _P, _I, _P, _Z, _P]),
+    "sd_adjacent_cosine_f32": (_I, [_P, _I, _I, _I, _F, _P, _P]),
+    "sd_sim_argmax_f32": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load libsd_hip.so once per process; raises if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP hot path is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is deliberately no CPU fallback."
+            )
+        lib = C.CDLL(str(LIB_PATH))
+        missing = [name for name in PROTOTYPES if not hasattr(lib, name)]
+        if missing:
+            raise RuntimeError(f"{LIB_PATH} lacks symbols declared in include/sd_hip.h: {missing}")
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.sd_abi_version() != SD_ABI_VERSION:
+            raise RuntimeError(f"libsd_hip.so ABI {lib.sd_abi_version()} != binding ABI {SD_ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    msg = load().sd_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int, what: str) -> None:
+    if status != SD_OK:
+        raise SdError(f"{what} failed (status {status}): {last_error()}")

@@ -1,0 +1,44 @@
+// Internal helpers shared by the HIP translation units of libsd_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "sd_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+int sd_set_error(int code, const char* fmt, ...);
+
+#define SD_CHECK_ARG(cond, ...)                            \
+  do {                                                     \
+    if (!(cond)) return sd_set_error(SD_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define SD_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return sd_set_error(SD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+// Kernel launches report configuration errors through hipGetLastError.
+#define SD_CHECK_LAUNCH(name)                                                           \
+  do {                                                                                  \
+    hipError_t e_ = hipGetLastError();                                                  \
+    if (e_ != hipSuccess)                                                               \
+      return sd_set_error(SD_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline bool sd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float sd_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float sd_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

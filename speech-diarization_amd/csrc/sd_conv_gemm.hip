@@ -1,0 +1,221 @@
+// Channel-last conv1d / pointwise conv as an implicit GEMM on the gfx950 matrix
+// cores, exact f32 (v_mfma_f32_32x32x2_f32), with the TDNNBlock epilogue
+// (bias -> ReLU -> eval-BatchNorm affine) of speechbrain's ECAPA-TDNN fused in.
+//
+// This is the operator behind every Conv1d the reference reaches through
+// EncoderClassifier.encode_batch [REF speech_encode.py:77]: the 80->C k=5 stem,
+// the C->C / 3C->3C pointwise convs, the dilated k=3 Res2Net convs, the SE and
+// attention 1x1 convs and the final FC.
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves, 2x2), each wave
+// 64x64 = 2x2 MFMA tiles of 32x32; K is walked in steps of 32 through a
+// double-buffered, register-prefetched LDS stage.  Rows are padded by one
+// 16-byte slot (row stride 36 floats) so the ds_read_b128 fragment reads of 16
+// lanes land on 16 distinct slots of the 256-byte bank row.
+//
+// Fragment trick: v_mfma_f32_32x32x2_f32 wants lane (i, h) to hold A[i][k=h].
+// Each lane reads FOUR consecutive k (one ds_read_b128) at k0 + 4h and feeds
+// element r to MFMA r, so MFMA r sums k in {k0 + r, k0 + 4 + r}; A and B use the
+// same permutation, and the sum over k is order independent up to rounding.
+#include "sd_common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int BK = 32;
+constexpr int LDP = BK + 4;  // padded LDS row, floats
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case SD_ACT_RELU: return fmaxf(v, 0.0f);
+    case SD_ACT_TANH: return tanhf(v);
+    case SD_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][BM][LDP]
+  float* Bs = smem + 2 * BM * LDP;  // [2][BN][LDP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  const int n_tiles = (p.cout + BN - 1) / BN;
+  const int tile_n = blockIdx.x % n_tiles;
+  const int tile_m = blockIdx.x / n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // staging role: 8 threads per 32-float row, 4 rows per thread
+  const int c4 = tid & 7;
+  const int r0 = tid >> 3;
+
+  int a_seg[4], a_t[4];
+  bool a_ok[4], b_ok[4];
+  const float* wrow[4];
+  const int ktot = p.taps * p.cin_pad;
+  const float* W = static_cast<const float*>(p.w);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int seg = (mm / p.T) * p.T;
+    a_seg[i] = seg;
+    a_t[i] = mm - seg;
+    const int n = n0 + r0 + 32 * i;
+    b_ok[i] = n < p.cout;
+    wrow[i] = W + (size_t)(b_ok[i] ? n : 0) * ktot + c4 * 4;
+  }
+  const int kpt = p.cin_pad / BK;
+  const int nk = p.taps * kpt;
+  const int half = p.taps / 2;
+  const float* X = p.x + p.a_col0;
+
+  f32x4 ra[4], rb[4];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto gload = [&](int kt) {
+    const int tap = kt / kpt;
+    const int c0 = (kt - tap * kpt) * BK + c4 * 4;
+    const int delta = (tap - half) * p.dil;
+    const bool cok = c0 < p.cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int tt = a_t[i] + delta;
+      tt = tt < 0 ? -tt : tt;
+      tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
+      ra[i] = (a_ok[i] && cok)
+                  ? *reinterpret_cast<const f32x4*>(X + (size_t)(a_seg[i] + tt) * p.lda + c0)
+                  : zero4;
+      rb[i] = b_ok[i] ? *reinterpret_cast<const f32x4*>(wrow[i] + kt * BK) : zero4;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* a = As + buf * BM * LDP;
+    float* b = Bs + buf * BN * LDP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDP + c4 * 4) = ra[i];
+      *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDP + c4 * 4) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 4;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) gload(kt + 1);
+
+    const float* a = As + cur * BM * LDP + (wm * 64 + frag_row) * LDP + frag_k;
+    const float* b = Bs + cur * BN * LDP + (wn * 64 + frag_row) * LDP + frag_k;
+#pragma unroll
+    for (int k8 = 0; k8 < BK / 8; ++k8) {
+      f32x4 fa[2], fb[2];
+      fa[0] = *reinterpret_cast<const f32x4*>(a + k8 * 8);
+      fa[1] = *reinterpret_cast<const f32x4*>(a + 32 * LDP + k8 * 8);
+      fb[0] = *reinterpret_cast<const f32x4*>(b + k8 * 8);
+      fb[1] = *reinterpret_cast<const f32x4*>(b + 32 * LDP + k8 * 8);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][r], fb[0][r], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][r], fb[1][r], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][r], fb[0][r], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][r], fb[1][r], acc[1][1], 0, 0, 0);
+      }
+    }
+
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane owns column n, 16 rows per MFMA tile
+  const int hrow = (lane >> 5) * 4;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+    if (n >= p.cout) continue;
+    const float bias_n = (p.bias && !p.bias_per_seg) ? p.bias[n] : 0.f;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float sh = p.shift ? p.shift[n] : 0.f;
+    const bool tee_n = p.tee && n >= p.tee_lo && n < p.tee_hi;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + hrow;
+        if (m >= p.M) continue;
+        float v = acc[mi][ni][r];
+        if (p.bias_per_seg) v += p.bias[(size_t)(m / p.T) * p.cout + n];
+        else v += bias_n;
+        v = apply_act(v, p.act);
+        v = v * sc + sh;
+        v = apply_act(v, p.act2);
+        p.y[(size_t)m * p.ldo + p.o_col0 + n] = v;
+        if (tee_n) {
+          float tv = v;
+          if (p.tee_add) tv += p.tee_add[(size_t)m * p.ld_ta + p.ta_col0 + (n - p.tee_lo)];
+          p.tee[(size_t)m * p.ldt + (n - p.tee_lo)] = tv;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
+  SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_f32: null args");
+  SD_CHECK_ARG(a->w_dtype == SD_DT_F32, "sd_conv1d_cl_f32: w_dtype %d not supported by the f32 operator", a->w_dtype);
+  SD_CHECK_ARG(a->x && a->w && a->y, "sd_conv1d_cl_f32: null x/w/y");
+  SD_CHECK_ARG(a->M > 0 && a->T > 0 && a->M % a->T == 0, "sd_conv1d_cl_f32: M=%d must be a positive multiple of T=%d", a->M, a->T);
+  SD_CHECK_ARG(a->cin > 0 && a->cin % 4 == 0, "sd_conv1d_cl_f32: cin=%d must be a positive multiple of 4", a->cin);
+  SD_CHECK_ARG(a->cin_pad >= a->cin && a->cin_pad % BK == 0, "sd_conv1d_cl_f32: cin_pad=%d must be >= cin and a multiple of %d", a->cin_pad, BK);
+  SD_CHECK_ARG(a->cout > 0, "sd_conv1d_cl_f32: cout=%d", a->cout);
+  SD_CHECK_ARG(a->taps >= 1 && (a->taps & 1), "sd_conv1d_cl_f32: taps=%d must be odd", a->taps);
+  SD_CHECK_ARG(a->dil >= 1, "sd_conv1d_cl_f32: dil=%d", a->dil);
+  SD_CHECK_ARG((a->taps / 2) * a->dil < a->T, "sd_conv1d_cl_f32: reflect padding %d needs T > pad (T=%d)", (a->taps / 2) * a->dil, a->T);
+  SD_CHECK_ARG(a->lda % 4 == 0 && a->a_col0 % 4 == 0 && a->a_col0 + a->cin <= a->lda,
+               "sd_conv1d_cl_f32: lda=%d a_col0=%d cin=%d (need multiples of 4, slice inside row)", a->lda, a->a_col0, a->cin);
+  SD_CHECK_ARG(a->o_col0 >= 0 && a->o_col0 + a->cout <= a->ldo, "sd_conv1d_cl_f32: output slice outside row (ldo=%d o_col0=%d cout=%d)", a->ldo, a->o_col0, a->cout);
+  SD_CHECK_ARG(sd_aligned16(a->x) && sd_aligned16(a->w), "sd_conv1d_cl_f32: x and w must be 16-byte aligned");
+  if (a->tee) {
+    SD_CHECK_ARG(a->tee_lo >= 0 && a->tee_lo < a->tee_hi && a->tee_hi <= a->cout && a->tee_hi - a->tee_lo <= a->ldt,
+                 "sd_conv1d_cl_f32: bad tee range [%d,%d) ldt=%d", a->tee_lo, a->tee_hi, a->ldt);
+    if (a->tee_add)
+      SD_CHECK_ARG(a->ta_col0 >= 0 && a->ta_col0 + (a->tee_hi - a->tee_lo) <= a->ld_ta, "sd_conv1d_cl_f32: tee_add slice outside row");
+  }
+  const long tiles_m = (a->M + BM - 1) / BM;
+  const long tiles_n = (a->cout + BN - 1) / BN;
+  SD_CHECK_ARG(tiles_m * tiles_n < (1L << 31), "sd_conv1d_cl_f32: grid too large");
+  const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), *a);
+  SD_CHECK_LAUNCH("conv_gemm_f32_kernel");
+  return SD_OK;
+}

@@ -1,0 +1,287 @@
+// Per-segment reductions and elementwise stages of the ECAPA-TDNN forward that are
+// not contractions: squeeze-excitation mean, SE gate * x + shortcut, global-context
+// mean/std, attentive statistics pooling (softmax over T, weighted mean/std), plus
+// the small cosine helpers of the callers (the call sites
+// are [REF anti_stick_diarize.py:102-104,176,430,433-434]).
+//
+// Layout everywhere: activations are [B*T][ld] f32, channel contiguous, so a thread
+// owns 4 consecutive channels (one 16-byte load per row) and walks time; a
+// workgroup is 64 channel groups x 4 row phases, combined through LDS in a fixed
+// order (results are run-to-run identical).
+#include "sd_common.h"
+
+namespace {
+
+constexpr int CG = 64;  // channel groups (of 4) per workgroup
+constexpr int RP = 4;   // row phases per workgroup
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// part[RP][CG] reduction helper: returns the fixed-order sum over row phases (valid for rp == 0)
+__device__ __forceinline__ f32x4 combine_sum(f32x4* part, int rp, int cg, f32x4 v) {
+  part[rp * CG + cg] = v;
+  __syncthreads();
+  f32x4 s = part[cg];
+#pragma unroll
+  for (int k = 1; k < RP; ++k) s += part[k * CG + cg];
+  __syncthreads();
+  return s;
+}
+__device__ __forceinline__ f32x4 combine_max(f32x4* part, int rp, int cg, f32x4 v) {
+  part[rp * CG + cg] = v;
+  __syncthreads();
+  f32x4 s = part[cg];
+#pragma unroll
+  for (int k = 1; k < RP; ++k) {
+    const f32x4 o = part[k * CG + cg];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], o[e]);
+  }
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(256) void seg_mean_std_kernel(const float* x, int ld, int col0, int T, int C,
+                                                           int want_std, float eps, float* out) {
+  __shared__ f32x4 part[RP * CG];
+  const int b = blockIdx.y;
+  const int cg = threadIdx.x & (CG - 1), rp = threadIdx.x >> 6;
+  const int c = (blockIdx.x * CG + cg) * 4;
+  const bool ok = c < C;
+  const float* base = x + (size_t)b * T * ld + col0 + (ok ? c : 0);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (ok)
+    for (int t = rp; t < T; t += RP) s += ld4(base + (size_t)t * ld);
+  s = combine_sum(part, rp, cg, s);
+  const float invT = 1.0f / (float)T;
+  const f32x4 mean = s * invT;
+  const int ostride = want_std ? 2 * C : C;
+  if (ok && rp == 0) st4(out + (size_t)b * ostride + c, mean);
+  if (!want_std) return;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (ok)
+    for (int t = rp; t < T; t += RP) {
+      const f32x4 d = ld4(base + (size_t)t * ld) - mean;
+      v += d * d;
+    }
+  v = combine_sum(part, rp, cg, v);
+  if (ok && rp == 0) {
+    f32x4 sd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sd[e] = sqrtf(fmaxf(v[e] * invT, eps));
+    st4(out + (size_t)b * ostride + C + c, sd);
+  }
+}
+
+__global__ __launch_bounds__(256) void se_scale_residual_kernel(const float* x, int ldx, const float* gate,
+                                                                const float* res, int ldr, int r_col0,
+                                                                float* y, int ldy, int y_col0,
+                                                                long M, int T, int C) {
+  const int c4n = C / 4;
+  const long total = M * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / c4n;
+    const int c = (int)(i - m * c4n) * 4;
+    const long b = m / T;
+    const f32x4 v = ld4(x + m * ldx + c) * ld4(gate + b * C + c) + ld4(res + m * ldr + r_col0 + c);
+    st4(y + m * ldy + y_col0 + c, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void asp_pool_kernel(const float* logit, int ldl, const float* h, int ldh,
+                                                       int T, int C, float eps, float* out) {
+  __shared__ f32x4 part[RP * CG];
+  const int b = blockIdx.y;
+  const int cg = threadIdx.x & (CG - 1), rp = threadIdx.x >> 6;
+  const int c = (blockIdx.x * CG + cg) * 4;
+  const bool ok = c < C;
+  const float* lb = logit + (size_t)b * T * ldl + (ok ? c : 0);
+  const float* hb = h + (size_t)b * T * ldh + (ok ? c : 0);
+  const float ninf = -INFINITY;
+  f32x4 mx = {ninf, ninf, ninf, ninf};
+  if (ok)
+    for (int t = rp; t < T; t += RP) {
+      const f32x4 l = ld4(lb + (size_t)t * ldl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], l[e]);
+    }
+  mx = combine_max(part, rp, cg, mx);
+  f32x4 den = {0.f, 0.f, 0.f, 0.f}, num = {0.f, 0.f, 0.f, 0.f};
+  if (ok)
+    for (int t = rp; t < T; t += RP) {
+      const f32x4 l = ld4(lb + (size_t)t * ldl);
+      const f32x4 hv = ld4(hb + (size_t)t * ldh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w = expf(l[e] - mx[e]);
+        den[e] += w;
+        num[e] += w * hv[e];
+      }
+    }
+  den = combine_sum(part, rp, cg, den);
+  num = combine_sum(part, rp, cg, num);
+  const f32x4 mu = num / den;
+  f32x4 var = {0.f, 0.f, 0.f, 0.f};
+  if (ok)
+    for (int t = rp; t < T; t += RP) {
+      const f32x4 l = ld4(lb + (size_t)t * ldl);
+      const f32x4 hv = ld4(hb + (size_t)t * ldh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w = expf(l[e] - mx[e]);
+        const float d = hv[e] - mu[e];
+        var[e] += w * d * d;
+      }
+    }
+  var = combine_sum(part, rp, cg, var);
+  if (ok && rp == 0) {
+    f32x4 sd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sd[e] = sqrtf(fmaxf(var[e] / den[e], eps));
+    st4(out + (size_t)b * 2 * C + c, mu);
+    st4(out + (size_t)b * 2 * C + C + c, sd);
+  }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, int ldx, int N, int D, float eps_add,
+                                                          int zero_guard, float* xn, int ldo) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= N) return;
+  const float* xr = x + (size_t)row * ldx;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) ss += xr[d] * xr[d];
+  ss = sd_wave_sum(ss);
+  float nrm = sqrtf(ss);
+  if (zero_guard && nrm == 0.f) nrm = 1.f;
+  nrm += eps_add;
+  float* o = xn + (size_t)row * ldo;
+  for (int d = lane; d < ldo; d += 64) o[d] = d < D ? xr[d] / nrm : 0.f;
+}
+
+__global__ __launch_bounds__(256) void adjacent_cosine_kernel(const float* x, int ldx, int N, int D, float eps, float* sims) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= N - 1) return;
+  const float* a = x + (size_t)i * ldx;
+  const float* b = a + ldx;
+  float dot = 0.f, na = 0.f, nb = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    dot += a[d] * b[d];
+    na += a[d] * a[d];
+    nb += b[d] * b[d];
+  }
+  dot = sd_wave_sum(dot); na = sd_wave_sum(na); nb = sd_wave_sum(nb);
+  if (lane == 0) sims[i] = dot / (sqrtf(na) * sqrtf(nb) + eps);
+}
+
+__global__ __launch_bounds__(256) void sim_argmax_kernel(const float* w, int ldw, int N, int D, const float* c, int ldc,
+                                                         int K, int32_t* best, float* score) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= N) return;
+  const float* wr = w + (size_t)i * ldw;
+  float bs = -INFINITY;
+  int bk = 0;
+  for (int k = 0; k < K; ++k) {
+    const float* cr = c + (size_t)k * ldc;
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot += wr[d] * cr[d];
+    dot = sd_wave_sum(dot);
+    if (dot > bs) { bs = dot; bk = k; }
+  }
+  if (lane == 0) {
+    best[i] = bk;
+    if (score) score[i] = bs;
+  }
+}
+
+int check_cl(const char* fn, const float* x, int ld, int col0, int C) {
+  SD_CHECK_ARG(x != nullptr, "%s: null input", fn);
+  SD_CHECK_ARG(C > 0 && C % 4 == 0 && ld % 4 == 0 && col0 % 4 == 0 && col0 >= 0 && col0 + C <= ld,
+               "%s: C=%d ld=%d col0=%d must be multiples of 4 with the slice inside the row", fn, C, ld, col0);
+  SD_CHECK_ARG(sd_aligned16(x), "%s: input must be 16-byte aligned", fn);
+  return SD_OK;
+}
+
+}  // namespace
+
+extern "C" int sd_seg_mean_f32(const float* x, int ld, int col0, int B, int T, int C, float* mean, sd_stream_t stream) {
+  if (int e = check_cl("sd_seg_mean_f32", x, ld, col0, C)) return e;
+  SD_CHECK_ARG(B > 0 && T > 0 && mean && sd_aligned16(mean), "sd_seg_mean_f32: B=%d T=%d / null or unaligned output", B, T);
+  dim3 grid((C / 4 + CG - 1) / CG, B);
+  hipLaunchKernelGGL(seg_mean_std_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, col0, T, C, 0, 0.f, mean);
+  SD_CHECK_LAUNCH("seg_mean_std_kernel");
+  return SD_OK;
+}
+
+extern "C" int sd_seg_mean_std_f32(const float* x, int ld, int col0, int B, int T, int C, float eps, float* stats,
+                                   sd_stream_t stream) {
+  if (int e = check_cl("sd_seg_mean_std_f32", x, ld, col0, C)) return e;
+  SD_CHECK_ARG(B > 0 && T > 0 && stats && sd_aligned16(stats), "sd_seg_mean_std_f32: B=%d T=%d / null or unaligned output", B, T);
+  dim3 grid((C / 4 + CG - 1) / CG, B);
+  hipLaunchKernelGGL(seg_mean_std_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, col0, T, C, 1, eps, stats);
+  SD_CHECK_LAUNCH("seg_mean_std_kernel");
+  return SD_OK;
+}
+
+extern "C" int sd_se_scale_residual_f32(const float* x, int ldx, const float* gate, const float* res, int ldr, int r_col0,
+                                        float* y, int ldy, int y_col0, int B, int T, int C, sd_stream_t stream) {
+  if (int e = check_cl("sd_se_scale_residual_f32(x)", x, ldx, 0, C)) return e;
+  if (int e = check_cl("sd_se_scale_residual_f32(res)", res, ldr, r_col0, C)) return e;
+  if (int e = check_cl("sd_se_scale_residual_f32(y)", y, ldy, y_col0, C)) return e;
+  SD_CHECK_ARG(gate && sd_aligned16(gate) && B > 0 && T > 0, "sd_se_scale_residual_f32: bad gate / B / T");
+  const long M = (long)B * T;
+  const long total = M * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(se_scale_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, ldx, gate, res, ldr, r_col0, y, ldy, y_col0, M, T, C);
+  SD_CHECK_LAUNCH("se_scale_residual_kernel");
+  return SD_OK;
+}
+
+extern "C" int sd_asp_pool_f32(const float* logit, int ldl, const float* h, int ldh, int B, int T, int C, float eps,
+                               float* out, sd_stream_t stream) {
+  if (int e = check_cl("sd_asp_pool_f32(logit)", logit, ldl, 0, C)) return e;
+  if (int e = check_cl("sd_asp_pool_f32(h)", h, ldh, 0, C)) return e;
+  SD_CHECK_ARG(B > 0 && T > 0 && out && sd_aligned16(out), "sd_asp_pool_f32: B=%d T=%d / null or unaligned output", B, T);
+  dim3 grid((C / 4 + CG - 1) / CG, B);
+  hipLaunchKernelGGL(asp_pool_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), logit, ldl, h, ldh, T, C, eps, out);
+  SD_CHECK_LAUNCH("asp_pool_kernel");
+  return SD_OK;
+}
+
+extern "C" int sd_l2norm_rows_f32(const float* x, int ldx, int N, int D, float eps_add, int sklearn_zero_guard,
+                                  float* xn, int ldo, sd_stream_t stream) {
+  SD_CHECK_ARG(N >= 0 && D > 0 && ldx >= D && ldo >= D, "sd_l2norm_rows_f32: N=%d D=%d ldx=%d ldo=%d", N, D, ldx, ldo);
+  if (N == 0) return SD_OK;
+  SD_CHECK_ARG(x && xn, "sd_l2norm_rows_f32: null pointer");
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, ldx, N, D, eps_add, sklearn_zero_guard, xn, ldo);
+  SD_CHECK_LAUNCH("l2norm_rows_kernel");
+  return SD_OK;
+}
+
+extern "C" int sd_adjacent_cosine_f32(const float* x, int ldx, int N, int D, float eps, float* sims, sd_stream_t stream) {
+  SD_CHECK_ARG(N >= 0 && D > 0 && ldx >= D, "sd_adjacent_cosine_f32: N=%d D=%d ldx=%d", N, D, ldx);
+  if (N < 2) return SD_OK;
+  SD_CHECK_ARG(x && sims, "sd_adjacent_cosine_f32: null pointer");
+  hipLaunchKernelGGL(adjacent_cosine_kernel, dim3((N - 1 + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, ldx, N, D, eps, sims);
+  SD_CHECK_LAUNCH("adjacent_cosine_kernel");
+  return SD_OK;
+}
+
+extern "C" int sd_sim_argmax_f32(const float* w, int ldw, int N, int D, const float* c, int ldc, int K,
+                                 int32_t* best, float* score, sd_stream_t stream) {
+  SD_CHECK_ARG(N >= 0 && D > 0 && K > 0 && ldw >= D && ldc >= D, "sd_sim_argmax_f32: N=%d D=%d K=%d", N, D, K);
+  if (N == 0) return SD_OK;
+  SD_CHECK_ARG(w && c && best, "sd_sim_argmax_f32: null pointer");
+  hipLaunchKernelGGL(sim_argmax_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w, ldw, N, D, c, ldc, K, best, score);
+  SD_CHECK_LAUNCH("sim_argmax_kernel");
+  return SD_OK;
+}

@@ -1,0 +1,211 @@
+"""Device-resident embedding engine: waveform [B, n] on the GPU -> 192-d embeddings on the GPU.
+
+This is the host side of the hot path: it owns the packed weights, the fbank plan
+and one workspace in HBM, and issues `sd_fbank_f32` + `sd_ecapa_forward_f32` on the
+current torch stream.  PyTorch is used for device memory and streams only; all
+arithmetic is in libsd_hip.so.
+
+The reference re-creates its feature transform and crosses host<->device three times
+per batch [REF speech_encode.py:17-38,76-77]; here tables and weights are uploaded
+once and a batch costs one H2D (waveforms) and one D2H (embeddings) at the API edge.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .features import FbankPlan
+from .synth import EcapaConfig, config_from_state_dict
+
+BN_EPS = 1e-5  # torch.nn.BatchNorm1d default, as used by speechbrain's BatchNorm1d
+K_ALIGN = 32   # K step of the conv/GEMM kernel
+
+
+def _np(x) -> np.ndarray:
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x, dtype=np.float32)
+
+
+def _pad_to(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def pack_conv_weight(w: np.ndarray) -> np.ndarray:
+    """[cout, cin, k] (torch Conv1d) -> [cout, k, cin_pad] f32, zero padded (kernel layout)."""
+    cout, cin, k = w.shape
+    cin_pad = _pad_to(cin, K_ALIGN)
+    out = np.zeros((cout, k, cin_pad), dtype=np.float32)
+    out[:, :, :cin] = np.transpose(w, (0, 2, 1))
+    return out
+
+
+def bn_affine(sd: dict, prefix: str):
+    g, b = _np(sd[f"{prefix}.weight"]), _np(sd[f"{prefix}.bias"])
+    rm, rv = _np(sd[f"{prefix}.running_mean"]), _np(sd[f"{prefix}.running_var"])
+    scale = (g.astype(np.float64) / np.sqrt(rv.astype(np.float64) + BN_EPS))
+    shift = b.astype(np.float64) - rm.astype(np.float64) * scale
+    return scale.astype(np.float32), shift.astype(np.float32)
+
+
+class EcapaWeights:
+    """ECAPA-TDNN weights packed for the HIP kernels and resident on one device."""
+
+    def __init__(self, state_dict: dict, device: torch.device):
+        self.device = device
+        self.cfg: EcapaConfig = config_from_state_dict(state_dict)
+        cfg = self.cfg
+        if len(set(cfg.channels[:-1])) != 1 or cfg.channels[-1] != cfg.n_blocks * cfg.channels[0]:
+            raise ValueError(f"unsupported ECAPA geometry {cfg.channels}: blocks must share one width and MFA = n_blocks * width")
+        self._keep: list[torch.Tensor] = []
+        sd = state_dict
+        W = N.sd_ecapa_weights()
+        W.w_dtype = N.SD_DT_F32
+        W.n_mels = cfg.input_size
+        W.channels = cfg.channels[0]
+        W.n_blocks = cfg.n_blocks
+        W.res2_scale = cfg.res2net_scale
+        W.mfa_channels = cfg.channels[-1]
+        W.att_channels = cfg.attention_channels
+        W.emb_dim = cfg.lin_neurons
+        W.asp_eps = 1e-12
+        self._fill(W.block0, _np(sd["blocks.0.conv.conv.weight"]), _np(sd["blocks.0.conv.conv.bias"]),
+                   bn_affine(sd, "blocks.0.norm.norm"), cfg.dilations[0])
+        for i in range(1, cfg.n_blocks + 1):
+            blk = W.blocks[i - 1]
+            p = f"blocks.{i}"
+            d = cfg.dilations[i]
+            self._fill(blk.tdnn1, _np(sd[f"{p}.tdnn1.conv.conv.weight"]), _np(sd[f"{p}.tdnn1.conv.conv.bias"]),
+                       bn_affine(sd, f"{p}.tdnn1.norm.norm"), 1)
+            for j in range(cfg.res2net_scale - 1):
+                q = f"{p}.res2net_block.blocks.{j}"
+                self._fill(blk.res2[j], _np(sd[f"{q}.conv.conv.weight"]), _np(sd[f"{q}.conv.conv.bias"]),
+                           bn_affine(sd, f"{q}.norm.norm"), d)
+            self._fill(blk.tdnn2, _np(sd[f"{p}.tdnn2.conv.conv.weight"]), _np(sd[f"{p}.tdnn2.conv.conv.bias"]),
+                       bn_affine(sd, f"{p}.tdnn2.norm.norm"), 1)
+            self._fill(blk.se1, _np(sd[f"{p}.se_block.conv1.conv.weight"]), _np(sd[f"{p}.se_block.conv1.conv.bias"]), None, 1)
+            self._fill(blk.se2, _np(sd[f"{p}.se_block.conv2.conv.weight"]), _np(sd[f"{p}.se_block.conv2.conv.bias"]), None, 1)
+        self._fill(W.mfa, _np(sd["mfa.conv.conv.weight"]), _np(sd["mfa.conv.conv.bias"]), bn_affine(sd, "mfa.norm.norm"), 1)
+        cm = cfg.channels[-1]
+        wa = _np(sd["asp.tdnn.conv.conv.weight"])  # [att, 3*cm, 1] acting on cat(h, mean, std)
+        self._fill(W.asp_tdnn_h, wa[:, :cm], None, bn_affine(sd, "asp.tdnn.norm.norm"), 1)
+        self._fill(W.asp_tdnn_g, wa[:, cm:], _np(sd["asp.tdnn.conv.conv.bias"]), None, 1)
+        self._fill(W.asp_conv, _np(sd["asp.conv.conv.weight"]), _np(sd["asp.conv.conv.bias"]), None, 1)
+        # asp_bn is an affine map in front of a linear layer: fold it into fc (float64 on the host)
+        s, t = bn_affine(sd, "asp_bn.norm")
+        wf = _np(sd["fc.conv.weight"]).astype(np.float64)[:, :, 0]
+        bf = _np(sd["fc.conv.bias"]).astype(np.float64)
+        w_fold = (wf * s.astype(np.float64)[None, :]).astype(np.float32)[:, :, None]
+        b_fold = (bf + wf @ t.astype(np.float64)).astype(np.float32)
+        self._fill(W.fc, w_fold, b_fold, None, 1)
+        self.struct = W
+        self.n_params = sum(int(np.prod(v.shape)) for k, v in sd.items() if "running" not in k and "num_batches" not in k)
+
+    def _dev(self, a: np.ndarray) -> int:
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        self._keep.append(t)
+        return t.data_ptr()
+
+    def _fill(self, L, w: np.ndarray, bias, affine, dil: int) -> None:
+        cout, cin, k = w.shape
+        L.w = self._dev(pack_conv_weight(w))
+        L.bias = self._dev(bias) if bias is not None else None
+        if affine is not None:
+            L.scale, L.shift = self._dev(affine[0]), self._dev(affine[1])
+        else:
+            L.scale, L.shift = None, None
+        L.cin, L.cin_pad, L.cout, L.taps, L.dil = cin, _pad_to(cin, K_ALIGN), cout, k, dil
+
+
+class EmbeddingEngine:
+    """fbank + ECAPA-TDNN on one GPU. Thread-safe (one forward at a time per engine)."""
+
+    def __init__(self, state_dict: dict, device="cuda", max_batch: int = 512):
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda":
+            raise RuntimeError(f"EmbeddingEngine runs on the GPU only (got device {self.device}); there is no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._lib = N.load()
+        self.max_batch = int(max_batch)
+        self._lock = threading.Lock()
+        with torch.cuda.device(self.device):
+            self.weights = EcapaWeights(state_dict, self.device)
+            self.plan = FbankPlan("speechbrain", n_mels=self.weights.cfg.input_size)
+        self.dim = self.weights.cfg.lin_neurons
+        self._ws = None
+        self._ws_key = None
+
+    # -- workspace: feats + fbank scratch + ECAPA activations, grown on demand
+    def _workspace(self, B: int, n: int):
+        key = (B, n)
+        if self._ws_key is not None and self._ws_key[0] >= B and self._ws_key[1] == n:
+            return self._ws
+        T = FbankPlan.num_frames(n)
+        n_mels = self.weights.cfg.input_size
+        feats = torch.empty((B * T, n_mels), dtype=torch.float32, device=self.device)
+        fb_bytes = self.plan.workspace_bytes(B, n)
+        fb_ws = torch.empty((max(fb_bytes, 256),), dtype=torch.uint8, device=self.device)
+        ec_bytes = int(self._lib.sd_ecapa_workspace_bytes(C.byref(self.weights.struct), B, T))
+        ec_ws = torch.empty((ec_bytes,), dtype=torch.uint8, device=self.device)
+        self._ws, self._ws_key = (feats, fb_ws, ec_ws), key
+        return self._ws
+
+    def embed(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav: f32 [B, n] on this engine's device -> f32 [B, dim] on the device (async on the current stream)."""
+        if wav.dim() != 2:
+            raise AssertionError("wav must be [B, n]")
+        if wav.device != self.device:
+            raise ValueError(f"wav is on {wav.device}, engine on {self.device}")
+        wav = wav.contiguous().float()
+        B, n = wav.shape
+        out = torch.empty((B, self.dim), dtype=torch.float32, device=self.device)
+        if B == 0:
+            return out
+        if n < 5 * 160:
+            raise ValueError(f"segment of {n} samples is too short: ECAPA's reflect padding needs at least 5 frames (800 samples)")
+        with self._lock, torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            mb = min(self.max_batch, B)
+            feats, fb_ws, ec_ws = self._workspace(mb, n)
+            T = FbankPlan.num_frames(n)
+            W = C.byref(self.weights.struct)
+            for lo in range(0, B, mb):
+                nb = min(mb, B - lo)
+                x = wav[lo:lo + nb]
+                N.check(self._lib.sd_fbank_f32(self.plan.handle, x.data_ptr(), nb, n, 1, feats.data_ptr(), feats.shape[1],
+                                               fb_ws.data_ptr(), fb_ws.numel(), stream), "sd_fbank_f32")
+                N.check(self._lib.sd_ecapa_forward_f32(W, feats.data_ptr(), nb, T, out[lo:lo + nb].data_ptr(),
+                                                       ec_ws.data_ptr(), ec_ws.numel(), stream), "sd_ecapa_forward_f32")
+        return out
+
+    def features(self, wav: torch.Tensor) -> torch.Tensor:
+        """The mean-normalised fbank the network consumes, [B, T, n_mels] (diagnostics / tests)."""
+        wav = wav.contiguous().float()
+        B, n = wav.shape
+        return fbank_device(wav, self.plan, mean_norm=True)
+
+
+def fbank_device(wav: torch.Tensor, plan: FbankPlan, mean_norm: bool = True) -> torch.Tensor:
+    """Run the HIP fbank on a device tensor [B, n] -> [B, T, n_mels]."""
+    if wav.dim() != 2:
+        raise AssertionError("wav must be [B, n]")
+    if wav.device.type != "cuda":
+        raise RuntimeError("fbank_device needs a GPU tensor; there is no CPU fallback")
+    lib = N.load()
+    wav = wav.contiguous().float()
+    B, n = wav.shape
+    T = FbankPlan.num_frames(n)
+    out = torch.empty((B, T, plan.n_mels), dtype=torch.float32, device=wav.device)
+    if B == 0:
+        return out
+    with torch.cuda.device(wav.device):
+        ws = torch.empty((max(plan.workspace_bytes(B, n), 256),), dtype=torch.uint8, device=wav.device)
+        stream = C.c_void_p(torch.cuda.current_stream(wav.device).cuda_stream)
+        N.check(lib.sd_fbank_f32(plan.handle, wav.data_ptr(), B, n, int(bool(mean_norm)), out.data_ptr(), plan.n_mels,
+                                 ws.data_ptr(), ws.numel(), stream), "sd_fbank_f32")
+    return out

@@ -1,0 +1,159 @@
+"""Thin torch-tensor wrappers over the layer / cosine operators of libsd_hip.so.
+
+Inputs and outputs are CUDA tensors; every call is asynchronous on the current
+torch stream.  These are the operators `sd_ecapa_forward_f32` is built from, exposed
+so that each can be parity-tested on its own, plus the cosine helpers used by the
+clustering-side callers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+_ACT = {None: N.SD_ACT_NONE, "none": N.SD_ACT_NONE, "relu": N.SD_ACT_RELU, "tanh": N.SD_ACT_TANH, "sigmoid": N.SD_ACT_SIGMOID}
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and t.device.type != "cuda":
+            raise RuntimeError("libsd_hip operators take GPU tensors; there is no CPU fallback")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def pack_weight(w: torch.Tensor | np.ndarray, device) -> torch.Tensor:
+    """[cout, cin, k] -> packed [cout, k, cin_pad] on `device`."""
+    from .engine import pack_conv_weight
+    w = w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
+    return torch.from_numpy(pack_conv_weight(w.astype(np.float32))).to(device)
+
+
+def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, T: int, *, cin: int, dil: int = 1, bias=None, bias_per_seg=False,
+              act=None, scale=None, shift=None, act2=None, a_col0: int = 0, out: torch.Tensor | None = None,
+              o_col0: int = 0, tee: torch.Tensor | None = None, tee_lo: int = 0, tee_hi: int = 0,
+              tee_add: torch.Tensor | None = None, ta_col0: int = 0) -> torch.Tensor:
+    """Channel-last conv1d ("same", reflect) with the fused TDNN epilogue. x: [M, lda], returns [M, ldo]."""
+    _need_cuda(x, w_packed, bias, scale, shift, out, tee, tee_add)
+    lib = N.load()
+    cout, taps, cin_pad = w_packed.shape
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, cout), dtype=torch.float32, device=x.device)
+    a = N.sd_conv_args()
+    a.x, a.lda, a.a_col0 = x.data_ptr(), x.stride(0), a_col0
+    a.w, a.w_dtype = w_packed.data_ptr(), N.SD_DT_F32
+    a.y, a.ldo, a.o_col0 = out.data_ptr(), out.stride(0), o_col0
+    a.M, a.T = M, T
+    a.cin, a.cin_pad, a.cout, a.taps, a.dil = cin, cin_pad, cout, taps, dil
+    a.bias, a.bias_per_seg = _ptr(bias), int(bool(bias_per_seg))
+    a.act, a.act2 = _ACT[act], _ACT[act2]
+    a.scale, a.shift = _ptr(scale), _ptr(shift)
+    if tee is not None:
+        a.tee, a.ldt, a.tee_lo, a.tee_hi = tee.data_ptr(), tee.stride(0), tee_lo, tee_hi
+        if tee_add is not None:
+            a.tee_add, a.ld_ta, a.ta_col0 = tee_add.data_ptr(), tee_add.stride(0), ta_col0
+    with torch.cuda.device(x.device):
+        N.check(lib.sd_conv1d_cl_f32(C.byref(a), _stream(x)), "sd_conv1d_cl_f32")
+    return out
+
+
+def seg_mean(x: torch.Tensor, B: int, T: int, col0: int = 0, C_: int | None = None) -> torch.Tensor:
+    _need_cuda(x)
+    C_ = x.shape[1] - col0 if C_ is None else C_
+    out = torch.empty((B, C_), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.load().sd_seg_mean_f32(x.data_ptr(), x.stride(0), col0, B, T, C_, out.data_ptr(), _stream(x)), "sd_seg_mean_f32")
+    return out
+
+
+def seg_mean_std(x: torch.Tensor, B: int, T: int, eps: float = 1e-12) -> torch.Tensor:
+    _need_cuda(x)
+    C_ = x.shape[1]
+    out = torch.empty((B, 2 * C_), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.load().sd_seg_mean_std_f32(x.data_ptr(), x.stride(0), 0, B, T, C_, C.c_float(eps), out.data_ptr(), _stream(x)),
+                "sd_seg_mean_std_f32")
+    return out
+
+
+def se_scale_residual(x: torch.Tensor, gate: torch.Tensor, res: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    _need_cuda(x, gate, res)
+    C_ = x.shape[1]
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        N.check(N.load().sd_se_scale_residual_f32(x.data_ptr(), x.stride(0), gate.data_ptr(), res.data_ptr(), res.stride(0), 0,
+                                                  y.data_ptr(), y.stride(0), 0, B, T, C_, _stream(x)), "sd_se_scale_residual_f32")
+    return y
+
+
+def asp_pool(logit: torch.Tensor, h: torch.Tensor, B: int, T: int, eps: float = 1e-12) -> torch.Tensor:
+    _need_cuda(logit, h)
+    C_ = h.shape[1]
+    out = torch.empty((B, 2 * C_), dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        N.check(N.load().sd_asp_pool_f32(logit.data_ptr(), logit.stride(0), h.data_ptr(), h.stride(0), B, T, C_, C.c_float(eps),
+                                         out.data_ptr(), _stream(h)), "sd_asp_pool_f32")
+    return out
+
+
+def l2norm_rows(x: torch.Tensor, eps_add: float = 0.0, sklearn_zero_guard: bool = False) -> torch.Tensor:
+    _need_cuda(x)
+    x = x.contiguous().float()
+    n, d = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        N.check(N.load().sd_l2norm_rows_f32(x.data_ptr(), d, n, d, C.c_float(eps_add), int(sklearn_zero_guard), out.data_ptr(), d,
+                                            _stream(x)), "sd_l2norm_rows_f32")
+    return out
+
+
+def cosine_affinity(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """sklearn `cosine_similarity(X)` semantics on the GPU: f32 [N, D] -> f32 [N, N]."""
+    _need_cuda(x)
+    lib = N.load()
+    x = x.contiguous().float()
+    n, d = x.shape
+    if out is None:
+        out = torch.empty((n, n), dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out
+    with torch.cuda.device(x.device):
+        ws_bytes = int(lib.sd_cosine_workspace_bytes(n, d))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        N.check(lib.sd_cosine_affinity_f32(x.data_ptr(), n, d, out.data_ptr(), out.stride(0), ws.data_ptr(), ws_bytes, _stream(x)),
+                "sd_cosine_affinity_f32")
+    return out
+
+
+def adjacent_cosine(x: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    _need_cuda(x)
+    x = x.contiguous().float()
+    n, d = x.shape
+    out = torch.empty((max(n - 1, 0),), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.load().sd_adjacent_cosine_f32(x.data_ptr(), d, n, d, C.c_float(eps), out.data_ptr(), _stream(x)),
+                "sd_adjacent_cosine_f32")
+    return out
+
+
+def sim_argmax(w: torch.Tensor, c: torch.Tensor):
+    _need_cuda(w, c)
+    w, c = w.contiguous().float(), c.contiguous().float()
+    n, d = w.shape
+    k = c.shape[0]
+    best = torch.empty((n,), dtype=torch.int32, device=w.device)
+    score = torch.empty((n,), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        N.check(N.load().sd_sim_argmax_f32(w.data_ptr(), d, n, d, c.data_ptr(), d, k, best.data_ptr(), score.data_ptr(), _stream(w)),
+                "sd_sim_argmax_f32")
+    return best, score

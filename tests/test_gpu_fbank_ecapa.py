@@ -1,0 +1,111 @@
+"""GPU parity of the fused fbank kernel and the ECAPA-TDNN forward against the CPU oracle.
+
+The oracle is float64 (ground truth); the HIP path is exact f32.  north_star's bar is
+1e-3 cosine on embeddings; the bounds asserted here are much tighter and written per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos_dist(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+@pytest.mark.parametrize("kind", ["torchaudio", "speechbrain"])
+@pytest.mark.parametrize("B,n", [(1, 32000), (5, 32000), (3, 16000), (4, 4999), (7, 3200), (2, 48123)])
+def test_fbank_matches_oracle(dev, kind, B, n):
+    from oracle import fbank_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import fbank_device
+    from speech_diarization_amd.features import FbankPlan
+    wav = synth.synthetic_segments(B * 7 + n, B, n)
+    wav[0, : n // 3] *= 0.01                      # a quiet stretch so the top_db floor is exercised
+    plan = FbankPlan(kind)
+    got = fbank_device(torch.from_numpy(wav).to(dev), plan, mean_norm=True).cpu().numpy()
+    ref = fbank_ref.fbank_batch_ref(wav) if kind == "torchaudio" else fbank_ref.speechbrain_fbank_ref(wav)
+    assert got.shape == ref.shape == (B, 1 + n // 160, 80)
+    # ln / dB of a 200-term f32 power sum: absolute error bound 2e-4 (dB scale: 1e-3)
+    tol = 2e-4 if kind == "torchaudio" else 1e-3
+    assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
+
+
+def test_fbank_known_answers(dev):
+    """all-zero waveform -> every bin log(eps) -> exactly 0 after mean-norm; pure tone -> peak at its mel bin."""
+    from speech_diarization_amd.engine import fbank_device
+    from speech_diarization_amd.features import FbankPlan, mel_filters_torchaudio
+    plan = FbankPlan("torchaudio")
+    z = fbank_device(torch.zeros(2, 8000, device=dev), plan, mean_norm=True)
+    assert z.abs().max() < 4e-6            # f32 sum/T of a constant is exact to ~1 ulp of ln(1e-6) = -13.8
+    raw = fbank_device(torch.zeros(1, 8000, device=dev), plan, mean_norm=False)
+    assert torch.allclose(raw, torch.full_like(raw, float(np.log(1e-6))), rtol=0, atol=1e-5)
+    t = np.arange(16000) / 16000.0
+    tone = (0.5 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)[None]
+    f = fbank_device(torch.from_numpy(tone).to(dev), plan, mean_norm=False).cpu().numpy()[0]
+    expect = int(np.argmax(mel_filters_torchaudio()[25]))          # 1000 Hz = DFT bin 25
+    assert abs(int(np.argmax(f[50])) - expect) <= 1
+
+
+def test_fbank_short_segments_and_errors(dev):
+    from oracle import fbank_ref
+    from speech_diarization_amd import synth, _native
+    from speech_diarization_amd.engine import fbank_device
+    from speech_diarization_amd.features import FbankPlan
+    plan = FbankPlan("speechbrain")
+    wav = synth.synthetic_segments(1, 9, 1600)             # T = 11 < 32: one tile row per utterance
+    got = fbank_device(torch.from_numpy(wav).to(dev), plan).cpu().numpy()
+    assert np.abs(got - fbank_ref.speechbrain_fbank_ref(wav)).max() < 1e-3
+    assert fbank_device(torch.zeros(0, 1600, device=dev), plan).shape == (0, 11, 80)
+    with pytest.raises(_native.SdError, match="reflect"):
+        fbank_device(torch.zeros(1, 150, device=dev), FbankPlan("torchaudio"))
+    with pytest.raises(AssertionError):
+        fbank_device(torch.zeros(1600, device=dev), plan)
+
+
+@pytest.mark.parametrize("width,B,n", [(64, 6, 16000), (128, 3, 32000)])
+def test_ecapa_small_geometry_matches_oracle(dev, width, B, n):
+    from oracle import ecapa_ref, fbank_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(21, synth.EcapaConfig.small(width))
+    wav = synth.synthetic_segments(3, B, n)
+    eng = EmbeddingEngine(sd, dev, max_batch=4)         # max_batch < B: exercises micro-batching
+    got = eng.embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    feats = fbank_ref.speechbrain_fbank_ref(wav)
+    ref = ecapa_ref.EcapaRef(sd, torch.float64).forward_features(torch.from_numpy(feats)).numpy()
+    assert got.shape == ref.shape == (B, 192)
+    assert _cos_dist(got, ref).max() < 1e-6
+    assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max()
+
+
+def test_ecapa_full_geometry_matches_oracle(dev):
+    """The spkrec-ecapa geometry (C=1024, 20.8 M parameters) on 2 s segments."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    wav = synth.synthetic_segments(0, 4, 32000)
+    eng = EmbeddingEngine(sd, dev)
+    got = eng.embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
+    cd = _cos_dist(got, ref)
+    assert cd.max() < 1e-5, cd           # north_star bar: 1e-3
+    assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max()
+
+
+def test_ecapa_zero_padding_counts_as_signal(dev):
+    """Zero-padded tails participate in mean-norm / SE / ASP exactly as in the reference
+    (no lengths are passed, [REF anti_stick_diarize.py:163-168])."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(21, synth.EcapaConfig.small(64))
+    wav = synth.synthetic_segments(9, 3, 24000)
+    wav[1, 9000:] = 0.0
+    wav[2, 20000:] = 0.0
+    got = EmbeddingEngine(sd, dev).embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
+    assert _cos_dist(got, ref).max() < 1e-6

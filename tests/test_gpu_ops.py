@@ -1,0 +1,166 @@
+"""GPU parity of the individual HIP operators against the CPU oracle / plain torch f64.
+
+All calls go through the C ABI (ctypes -> libsd_hip.so).  Tolerances are stated per test:
+the operators are exact-f32 (fma chains on the f32 matrix cores), the references are
+float64, so the bound is f32 rounding of a K-term sum.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_conv_cl(x, w, b, T, dil):
+    """x [M, cin] f64 channel-last, w [cout, cin, k]; 'same' reflect conv per segment."""
+    M, cin = x.shape
+    B = M // T
+    xt = x.view(B, T, cin).transpose(1, 2)
+    pad = dil * (w.shape[2] - 1) // 2
+    if pad:
+        xt = F.pad(xt, (pad, pad), mode="reflect")
+    y = F.conv1d(xt, w, b, dilation=dil)
+    return y.transpose(1, 2).reshape(M, -1)
+
+
+@pytest.mark.parametrize("B,T,cin,cout,k,dil", [
+    (3, 201, 1024, 1024, 1, 1),     # pointwise, tile-aligned N
+    (5, 101, 128, 128, 3, 3),       # Res2Net conv, M not a tile multiple, segments straddle tiles
+    (2, 201, 80, 256, 5, 1),        # stem: cin not a multiple of the K step
+    (7, 1, 1024, 128, 1, 1),        # SE squeeze: T = 1, tiny M
+    (4, 33, 256, 192, 1, 1),        # cout not a multiple of the N tile
+])
+def test_conv1d_cl_matches_torch(dev, B, T, cin, cout, k, dil):
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B * T, cin, generator=g, dtype=torch.float64)
+    w = torch.randn(cout, cin, k, generator=g, dtype=torch.float64) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    scale = torch.rand(cout, generator=g, dtype=torch.float64) + 0.5
+    shift = torch.randn(cout, generator=g, dtype=torch.float64)
+    ref = torch.relu(_ref_conv_cl(x, w, b, T, dil)) * scale + shift
+    got = ops.conv1d_cl(x.float().to(dev), ops.pack_weight(w.float(), dev), T, cin=cin, dil=dil, bias=b.float().to(dev),
+                        act="relu", scale=scale.float().to(dev), shift=shift.float().to(dev))
+    torch.cuda.synchronize()
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv1d_cl_slices_tee_and_per_segment_bias(dev):
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, C, hid = 3, 57, 256, 32
+    xbig = torch.randn(B * T, C, generator=g, dtype=torch.float64)
+    w = torch.randn(hid, hid, 3, generator=g, dtype=torch.float64) / 10
+    segb = torch.randn(B, hid, generator=g, dtype=torch.float64)
+    x_d = xbig.float().to(dev)
+    out = torch.zeros(B * T, C, device=dev)
+    tee = torch.zeros(B * T, hid, device=dev)
+    # input = column slice [64, 96), output into column slice [32, 64), tee = y + xbig[:, 96:128]
+    ops.conv1d_cl(x_d, ops.pack_weight(w.float(), dev), T, cin=hid, dil=2, bias=segb.float().to(dev), bias_per_seg=True,
+                  act="relu", act2="tanh", a_col0=64, out=out, o_col0=32, tee=tee, tee_lo=0, tee_hi=hid, tee_add=x_d, ta_col0=96)
+    torch.cuda.synchronize()
+    y = _ref_conv_cl(xbig[:, 64:96].contiguous(), w, None, T, 2) + segb.repeat_interleave(T, dim=0)
+    y = torch.tanh(torch.relu(y))
+    assert (out[:, 32:64].cpu().double() - y).abs().max() < 1e-5
+    assert out[:, :32].abs().max() == 0 and out[:, 64:].abs().max() == 0
+    assert (tee.cpu().double() - (y + xbig[:, 96:128])).abs().max() < 1e-5
+
+
+def test_conv1d_cl_rejects_bad_arguments(dev):
+    from speech_diarization_amd import ops, _native
+    x = torch.zeros(10, 6, device=dev)
+    w = torch.zeros(4, 1, 32, device=dev)
+    with pytest.raises(_native.SdError, match="multiple of 4"):
+        ops.conv1d_cl(x, w, 5, cin=6)
+    x = torch.zeros(8, 8, device=dev)
+    w3 = torch.zeros(4, 3, 32, device=dev)
+    with pytest.raises(_native.SdError, match="reflect padding"):
+        ops.conv1d_cl(x, w3, 2, cin=8, dil=2)   # pad 2 >= T 2
+
+
+def test_segment_reductions_and_se(dev):
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, T, C = 5, 201, 1024
+    x = torch.randn(B * T, C, generator=g, dtype=torch.float64) * 3 + 1
+    xd = x.float().to(dev)
+    m = ops.seg_mean(xd, B, T)
+    ms = ops.seg_mean_std(xd, B, T)
+    xr = x.view(B, T, C)
+    assert (m.cpu().double() - xr.mean(1)).abs().max() < 1e-5
+    assert (ms[:, :C].cpu().double() - xr.mean(1)).abs().max() < 1e-5
+    assert (ms[:, C:].cpu().double() - xr.std(1, unbiased=False)).abs().max() < 1e-5
+    gate = torch.rand(B, C, generator=g, dtype=torch.float64)
+    res = torch.randn(B * T, C, generator=g, dtype=torch.float64)
+    y = ops.se_scale_residual(xd, gate.float().to(dev), res.float().to(dev), B, T)
+    ref = x * gate.repeat_interleave(T, 0) + res
+    assert (y.cpu().double() - ref).abs().max() < 1e-5
+
+
+def test_std_clamp_on_constant_input(dev):
+    """constant-in-time features -> variance 0 -> sqrt(clamp(1e-12)) = 1e-6 exactly (SURVEY 8c KAT)."""
+    from speech_diarization_amd import ops
+    B, T, C = 2, 50, 64
+    x = torch.full((B * T, C), 0.75, device=dev)
+    ms = ops.seg_mean_std(x, B, T, eps=1e-12)
+    assert torch.all(ms[:, :C] == 0.75)
+    assert torch.allclose(ms[:, C:], torch.full((B, C), 1e-6, device=dev), rtol=1e-6, atol=0)
+
+
+def test_asp_pool(dev):
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, T, C = 4, 201, 768
+    logit = torch.randn(B * T, C, generator=g, dtype=torch.float64) * 4
+    h = torch.randn(B * T, C, generator=g, dtype=torch.float64)
+    out = ops.asp_pool(logit.float().to(dev), h.float().to(dev), B, T)
+    a = torch.softmax(logit.view(B, T, C), dim=1)
+    hv = h.view(B, T, C)
+    mu = (a * hv).sum(1)
+    sd = torch.sqrt((a * (hv - mu[:, None]) ** 2).sum(1).clamp(min=1e-12))
+    assert (out[:, :C].cpu().double() - mu).abs().max() < 1e-5
+    assert (out[:, C:].cpu().double() - sd).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("n,d", [(1, 192), (37, 192), (300, 192), (129, 50)])
+def test_cosine_affinity_matches_sklearn(dev, n, d):
+    from sklearn.metrics.pairwise import cosine_similarity
+    from speech_diarization_amd import ops
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    if n > 5:
+        x[3] = 0.0          # zero row -> zero similarity row / column, diagonal 0 (sklearn semantics)
+        x[5] = 2.5 * x[4]   # colinear rows -> 1
+    got = ops.cosine_affinity(torch.from_numpy(x).to(dev)).cpu().numpy()
+    ref = cosine_similarity(x)
+    assert got.dtype == np.float32 and got.shape == (n, n)
+    assert np.abs(got - ref).max() < 2e-6
+    if n > 5:
+        assert np.all(got[3] == 0) and np.all(got[:, 3] == 0)
+        assert abs(got[4, 5] - 1.0) < 1e-6
+
+
+def test_cosine_affinity_identity_and_empty(dev):
+    from speech_diarization_amd import ops
+    eye = torch.eye(192, device=dev)
+    k = ops.cosine_affinity(eye)
+    assert torch.equal(k, eye)
+    assert ops.cosine_affinity(torch.zeros(0, 192, device=dev)).shape == (0, 0)
+
+
+def test_adjacent_cosine_and_argmax(dev):
+    from oracle.pipeline_ref import adjacent_cosine_ref, assign_windows_ref
+    from speech_diarization_amd import ops
+    rng = np.random.default_rng(0)
+    e = rng.standard_normal((41, 192)).astype(np.float32)
+    got = ops.adjacent_cosine(torch.from_numpy(e).to(dev)).cpu().numpy()
+    assert np.abs(got - adjacent_cosine_ref(e.astype(np.float64))).max() < 1e-6
+    c = rng.standard_normal((5, 192)).astype(np.float32)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    wn = ops.l2norm_rows(torch.from_numpy(e).to(dev), eps_add=1e-8)
+    best, score = ops.sim_argmax(wn, torch.from_numpy(c).to(dev))
+    ref_best, ref_sim = assign_windows_ref(e.astype(np.float64), c.astype(np.float64))
+    assert np.array_equal(best.cpu().numpy(), ref_best)
+    assert np.abs(score.cpu().numpy() - ref_sim.max(1)).max() < 1e-6
