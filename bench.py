@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: segment-embeddings/sec on synthetic 2 s @ 16 kHz segments.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over this rank's batch of synthetic segments
+(BASELINE.json configs[1]: 10 000 segments of 32 000 samples, already resident in HBM):
+HIP fbank -> HIP ECAPA-TDNN forward (spkrec-ecapa geometry, 20.8 M random-init parameters)
+-> [N > 1: RCCL all-gather of the 192-d embeddings] -> cosine affinity of this rank's row
+block on-device.  Weak scaling: every rank owns `--segments` segments.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the implicit-GEMM
+conv on the f32 matrix cores); `roofline_fbank` is the HBM-bound fbank kernel.  Kernel
+durations are measured live with HIP events on the launch stream (sd_profile_*).
+`cpu_baseline` times the CPU oracle (torch f32) on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0          # HBM3E spec
+SAMPLES = 32000                # 2 s @ 16 kHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--segments", type=int, default=10000, help="segments per rank per step")
+    ap.add_argument("--micro-batch", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(state_dict, wav_dev, budget_s):
+    """The CPU oracle (torch f32: torch.stft fbank + F.conv1d ECAPA) on the host cores, batch 32
+    (the reference's embed_segments batch, [REF anti_stick_diarize.py:134])."""
+    from oracle.ecapa_ref import EcapaRef
+    from oracle.pipeline_ref import encode_batch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = EcapaRef(state_dict, torch.float32)
+    batch = 32
+    sample = wav_dev[: 8 * batch].cpu().numpy()
+    encode_batch_ref(state_dict, sample[:batch], torch.float32, net)       # warm-up
+    done, t0 = 0, time.perf_counter()
+    while done < sample.shape[0] and (time.perf_counter() - t0) < budget_s:
+        encode_batch_ref(state_dict, sample[done:done + batch], torch.float32, net)
+        done += batch
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "segments/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} of the same synthetic 2 s segments, batch {batch}, torch-CPU f32 oracle, {dt:.1f} s"}
+
+
+def load_traffic():
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return {}
+
+
+def main():
+    args = parse()
+    from speech_diarization_amd import _native, ops, synth
+    from speech_diarization_amd import dist as sdist
+    from speech_diarization_amd.engine import EmbeddingEngine
+
+    rank, local_rank, world = sdist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    _native.load()
+
+    state_dict = synth.make_ecapa_state_dict(1234)
+    engine = EmbeddingEngine(state_dict, dev, max_batch=args.micro_batch)
+    S = args.segments
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    wav = (torch.randn((S, SAMPLES), generator=gen, device=dev, dtype=torch.float32) * 0.1).clamp_(-1.0, 1.0)
+    n_total = S * world
+    lo, hi = sdist.row_block(n_total, rank, world)
+    aff = torch.empty((hi - lo, n_total), dtype=torch.float32, device=dev)
+
+    def step():
+        emb = engine.embed(wav)
+        full = sdist.all_gather_embeddings(emb, n_total)
+        ops.cosine_affinity(full, out=aff, rows=(lo, hi))
+        return emb
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _native.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb = step()
+    fence()
+    dt = time.perf_counter() - t0
+    conv_ms, conv_n, conv_flops = _native.profile_read(_native.SD_PROF_CONV_GEMM)
+    fb_ms, fb_n, fb_bytes = _native.profile_read(_native.SD_PROF_FBANK)
+    _native.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not bool(torch.isfinite(emb).all()):
+        raise SystemExit("non-finite embeddings")
+
+    if rank == 0:
+        traffic = load_traffic()
+        value = n_total * args.steps / dt
+        conv_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        fb_gbs = fb_bytes / (fb_ms * 1e-3) / 1e9 if fb_ms > 0 else 0.0
+        out = {
+            "metric": "segment-embeddings/sec (2 s @16 kHz)",
+            "value": value,
+            "unit": "segments/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: 10k synthetic 2 s@16 kHz segments per GPU, HIP fbank + ECAPA-TDNN forward "
+                            "(C=1024 spkrec-ecapa geometry, random-init seed 1234), all-gather of 192-d embeddings, "
+                            "cosine affinity of the rank's row block on-device",
+                "segments_per_gpu": S, "samples_per_segment": SAMPLES, "micro_batch": args.micro_batch,
+                "affinity_rows_per_gpu": hi - lo, "affinity_cols": n_total,
+                "parallelism": f"segments sharded over {world} GPU(s), one all_gather_into_tensor per step",
+            },
+            "roofline": {
+                "kernel": "conv_gemm_f32_kernel", "bound": "mfma",
+                "achieved": conv_tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": conv_tflops / F32_MFMA_PEAK_TFLOPS,
+                "traffic": traffic.get("conv_gemm_f32_kernel"),
+                "launches": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
+                "flops_per_launch": conv_flops / max(conv_n, 1),
+                "share_of_step_time": conv_ms * 1e-3 / dt,
+            },
+            "roofline_fbank": {
+                "kernel": "fbank_logmel_kernel", "bound": "hbm",
+                "achieved": fb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb_gbs / HBM_PEAK_GBS,
+                "traffic": traffic.get("fbank_logmel_kernel"),
+                "launches": fb_n, "avg_launch_ms": fb_ms / max(fb_n, 1),
+                "bytes_per_launch": fb_bytes / max(fb_n, 1),
+                "share_of_step_time": fb_ms * 1e-3 / dt,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(state_dict, wav, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

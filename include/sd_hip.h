@@ -51,6 +51,17 @@ const char* sd_last_error(void);
 /* number of HIP devices visible, or negative error */
 int sd_device_count(void);
 
+/* Per-kernel timing with HIP events recorded on the launch stream, for bench.py's
+ * roofline figures.  While enabled every launch of the named kernel families is
+ * bracketed by two events; sd_profile_read synchronises them and returns the summed
+ * duration, the launch count and the summed algorithmic work (flops for
+ * SD_PROF_CONV_GEMM, bytes for SD_PROF_FBANK) since the last sd_profile_enable(1). */
+#define SD_PROF_CONV_GEMM 0
+#define SD_PROF_FBANK 1
+#define SD_PROF_KINDS 2
+int sd_profile_enable(int on);
+int sd_profile_read(int kind, double* ms, long long* launches, double* work);
+
 /* ------------------------------------------------------------------ fbank */
 
 /* pad_mode */
@@ -191,6 +202,10 @@ int sd_l2norm_rows_f32(const float* x, int ldx, int N, int D, float eps_add, int
 size_t sd_cosine_workspace_bytes(int N, int D);
 int sd_cosine_affinity_f32(const float* x, int N, int D, float* out, int ldo,
                            void* ws_dev, size_t ws_bytes, sd_stream_t stream);
+/* rows [row_lo, row_hi) of the same matrix -> out [(row_hi-row_lo)][N]; the unit one rank
+ * computes when the affinity is row-block sharded (same workspace size). */
+int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row_lo, int row_hi, float* out, int ldo,
+                                void* ws_dev, size_t ws_bytes, sd_stream_t stream);
 /* sims[i] = <x[i], x[i+1]> / (||x[i]|| * ||x[i+1]|| + eps), i < N-1 */
 int sd_adjacent_cosine_f32(const float* x, int ldx, int N, int D, float eps, float* sims, sd_stream_t stream);
 /* best[i] = argmax_k <w[i], c[k]> (first max wins, numpy argmax), score[i] = max */

@@ -21,6 +21,18 @@ SD_DT_F32, SD_DT_F16 = 0, 1
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
 SD_ABI_VERSION = 1
+SD_PROF_CONV_GEMM, SD_PROF_FBANK = 0, 1
+
+
+def profile_enable(on: bool) -> None:
+    check(load().sd_profile_enable(int(on)), "sd_profile_enable")
+
+
+def profile_read(kind: int):
+    """(total_ms, launches, work) of one kernel family since profile_enable(True)."""
+    ms, n, w = C.c_double(), C.c_longlong(), C.c_double()
+    check(load().sd_profile_read(kind, C.byref(ms), C.byref(n), C.byref(w)), "sd_profile_read")
+    return ms.value, n.value, w.value
 
 
 class SdError(RuntimeError):
@@ -80,6 +92,8 @@ PROTOTYPES = {
     "sd_abi_version": (_I, []),
     "sd_last_error": (C.c_char_p, []),
     "sd_device_count": (_I, []),
+    "sd_profile_enable": (_I, [_I]),
+    "sd_profile_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "sd_fbank_plan_create": (_P, [_P, _I, _I, _P, _I, _I, _I, _F, _F]),
     "sd_fbank_plan_destroy": (None, [_P]),
     "sd_fbank_num_frames": (_I, [_P, _I]),
@@ -95,6 +109,7 @@ PROTOTYPES = {
     "sd_l2norm_rows_f32": (_I, [_P, _I, _I, _I, _F, _I, _P, _I, _P]),
     "sd_cosine_workspace_bytes": (_Z, [_I, _I]),
     "sd_cosine_affinity_f32": (_I, [_P, _I, _I, _P, _I, _P, _Z, _P]),
+    "sd_cosine_affinity_rows_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_adjacent_cosine_f32": (_I, [_P, _I, _I, _I, _F, _P, _P]),
     "sd_sim_argmax_f32": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
 }

@@ -1,5 +1,7 @@
 // Error reporting, library identity and the N x N cosine-affinity entry point.
 #include "sd_common.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 thread_local char g_err[512] = "";
@@ -23,6 +25,64 @@ extern "C" int sd_device_count(void) {
   return n;
 }
 
+// ---------------------------------------------------------------- event profiling
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double work; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;       // records in use
+std::vector<hipEvent_t> g_pool;    // recycled events
+std::mutex g_prof_mu;
+
+hipEvent_t prof_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+SdProfScope::SdProfScope(int kind, hipStream_t s, double work) : slot(-1), stream(s) {
+  if (!g_prof_on) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r{prof_event(), prof_event(), kind, work};
+  if (!r.a || !r.b) return;
+  (void)hipEventRecord(r.a, s);
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+
+SdProfScope::~SdProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].b, stream);
+}
+
+extern "C" int sd_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (ProfRec& r : g_prof) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return SD_OK;
+}
+
+extern "C" int sd_profile_read(int kind, double* ms, long long* launches, double* work) {
+  SD_CHECK_ARG(kind >= 0 && kind < SD_PROF_KINDS && ms && launches && work, "sd_profile_read: bad arguments");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double t = 0.0, w = 0.0;
+  long long n = 0;
+  for (ProfRec& r : g_prof) {
+    if (r.kind != kind) continue;
+    SD_CHECK_HIP(hipEventSynchronize(r.b));
+    float dt = 0.f;
+    SD_CHECK_HIP(hipEventElapsedTime(&dt, r.a, r.b));
+    t += dt; w += r.work; ++n;
+  }
+  *ms = t; *launches = n; *work = w;
+  return SD_OK;
+}
+
 static int pad32(int d) { return (d + 31) & ~31; }
 
 extern "C" size_t sd_cosine_workspace_bytes(int N, int D) {
@@ -37,8 +97,17 @@ extern "C" size_t sd_cosine_workspace_bytes(int N, int D) {
 // cores through the same implicit-GEMM operator as the pointwise convs.
 extern "C" int sd_cosine_affinity_f32(const float* x, int N, int D, float* out, int ldo,
                                       void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
+  return sd_cosine_affinity_rows_f32(x, N, D, 0, N, out, ldo, ws_dev, ws_bytes, stream);
+}
+
+// Rows [row_lo, row_hi) of the same matrix: out [(row_hi-row_lo)][N].  This is the unit a
+// rank computes when the affinity is row-block sharded across GPUs (the N x N result is
+// never moved over xGMI, only the N x D embeddings are).
+extern "C" int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row_lo, int row_hi, float* out, int ldo,
+                                           void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
   SD_CHECK_ARG(N >= 0 && D > 0, "sd_cosine_affinity_f32: N=%d D=%d", N, D);
-  if (N == 0) return SD_OK;
+  SD_CHECK_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= N, "sd_cosine_affinity_rows_f32: bad row block [%d,%d) of %d", row_lo, row_hi, N);
+  if (N == 0 || row_lo == row_hi) return SD_OK;
   SD_CHECK_ARG(x && out && ws_dev, "sd_cosine_affinity_f32: null pointer");
   SD_CHECK_ARG(ldo >= N, "sd_cosine_affinity_f32: ldo=%d < N=%d", ldo, N);
   if (ws_bytes < sd_cosine_workspace_bytes(N, D))
@@ -49,10 +118,10 @@ extern "C" int sd_cosine_affinity_f32(const float* x, int N, int D, float* out, 
   int e = sd_l2norm_rows_f32(x, D, N, D, 0.f, 1, xn, Dp, stream);
   if (e != SD_OK) return e;
   sd_conv_args a = {};
-  a.x = xn; a.lda = Dp; a.a_col0 = 0;
+  a.x = xn + (size_t)row_lo * Dp; a.lda = Dp; a.a_col0 = 0;
   a.w = xn; a.w_dtype = SD_DT_F32;
   a.y = out; a.ldo = ldo; a.o_col0 = 0;
-  a.M = N; a.T = 1;
+  a.M = row_hi - row_lo; a.T = 1;
   a.cin = Dp; a.cin_pad = Dp; a.cout = N; a.taps = 1; a.dil = 1;
   a.act = SD_ACT_NONE; a.act2 = SD_ACT_NONE;
   return sd_conv1d_cl_f32(&a, stream);

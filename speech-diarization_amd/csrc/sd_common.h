@@ -30,6 +30,14 @@ int sd_set_error(int code, const char* fmt, ...);
       return sd_set_error(SD_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
+// ---- optional per-kernel timing with HIP events on the launch stream (sd_profile_* in sd_hip.h)
+struct SdProfScope {
+  SdProfScope(int kind, hipStream_t stream, double work);
+  ~SdProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
 static inline bool sd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float sd_wave_max(float v) {

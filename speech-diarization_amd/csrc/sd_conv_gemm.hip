@@ -214,8 +214,12 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds,
-                     static_cast<hipStream_t>(stream), *a);
+  {
+    SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream),
+                     2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
+    hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), *a);
+  }
   SD_CHECK_LAUNCH("conv_gemm_f32_kernel");
   return SD_OK;
 }

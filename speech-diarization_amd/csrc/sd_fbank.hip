@@ -400,7 +400,11 @@ extern "C" int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(fbank_logmel_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  {
+    // algorithmic bytes: waveform read once + log-mel written once (192 320 B per 2 s segment)
+    SdProfScope prof(SD_PROF_FBANK, stream, (double)B * ((double)n * 4.0 + (double)T * plan->n_mels * 4.0));
+    hipLaunchKernelGGL(fbank_logmel_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  }
   SD_CHECK_LAUNCH("fbank_logmel_kernel");
   const int use_floor = plan->log_mode == SD_LOG_DB_TOPDB && plan->top_db >= 0.f;
   if (use_floor || mean_norm) {

@@ -117,21 +117,23 @@ def l2norm_rows(x: torch.Tensor, eps_add: float = 0.0, sklearn_zero_guard: bool 
     return out
 
 
-def cosine_affinity(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-    """sklearn `cosine_similarity(X)` semantics on the GPU: f32 [N, D] -> f32 [N, N]."""
+def cosine_affinity(x: torch.Tensor, out: torch.Tensor | None = None, rows: tuple[int, int] | None = None) -> torch.Tensor:
+    """sklearn `cosine_similarity(X)` semantics on the GPU: f32 [N, D] -> f32 [N, N]
+    (or rows [lo, hi) of it -> [hi-lo, N] when `rows` is given)."""
     _need_cuda(x)
     lib = N.load()
     x = x.contiguous().float()
     n, d = x.shape
+    lo, hi = (0, n) if rows is None else rows
     if out is None:
-        out = torch.empty((n, n), dtype=torch.float32, device=x.device)
-    if n == 0:
+        out = torch.empty((hi - lo, n), dtype=torch.float32, device=x.device)
+    if n == 0 or hi == lo:
         return out
     with torch.cuda.device(x.device):
         ws_bytes = int(lib.sd_cosine_workspace_bytes(n, d))
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-        N.check(lib.sd_cosine_affinity_f32(x.data_ptr(), n, d, out.data_ptr(), out.stride(0), ws.data_ptr(), ws_bytes, _stream(x)),
-                "sd_cosine_affinity_f32")
+        N.check(lib.sd_cosine_affinity_rows_f32(x.data_ptr(), n, d, lo, hi, out.data_ptr(), out.stride(0), ws.data_ptr(), ws_bytes,
+                                                _stream(x)), "sd_cosine_affinity_rows_f32")
     return out
 
 
