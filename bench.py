@@ -47,17 +47,35 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(affinity, cgroup cpu quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(state_dict, wav_dev, budget_s):
     """The CPU oracle (torch f32: torch.stft fbank + F.conv1d ECAPA) on the host cores, batch 32
     (the reference's embed_segments batch, [REF anti_stick_diarize.py:134])."""
     from oracle.ecapa_ref import EcapaRef
     from oracle.pipeline_ref import encode_batch_ref
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     net = EcapaRef(state_dict, torch.float32)
     batch = 32
-    sample = wav_dev[: 8 * batch].cpu().numpy()
-    encode_batch_ref(state_dict, sample[:batch], torch.float32, net)       # warm-up
+    sample = wav_dev[: 16 * batch].cpu().numpy()
+    encode_batch_ref(state_dict, sample[:4], torch.float32, net)           # warm-up (allocator, oneDNN primitives)
     done, t0 = 0, time.perf_counter()
     while done < sample.shape[0] and (time.perf_counter() - t0) < budget_s:
         encode_batch_ref(state_dict, sample[done:done + batch], torch.float32, net)

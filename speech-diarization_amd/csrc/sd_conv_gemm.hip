@@ -25,6 +25,8 @@ constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int BK = 32;
 constexpr int LDP = BK + 4;  // padded LDS row, floats
+constexpr int LDC = BN + 4;  // padded row of the epilogue's C tile in LDS
+static_assert(BM * LDC <= 2 * (BM + BN) * LDP, "C tile must fit in the operand stage");
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -35,7 +37,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p, const int vec) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM][LDP]
   float* Bs = smem + 2 * BM * LDP;  // [2][BN][LDP]
@@ -50,49 +52,61 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   const int tile_m = blockIdx.x / n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // staging role: 8 threads per 32-float row, 4 rows per thread
+  // staging role: 8 threads per 32-float row, 4 rows per thread.  Rows past M and output
+  // channels past cout are clamped to the last valid one (their results are never stored)
+  // and columns past cin re-read column 0 against the zero-filled weight padding, so every
+  // load is unconditional: no branches and no selects in the K loop.
   const int c4 = tid & 7;
   const int r0 = tid >> 3;
 
   int a_seg[4], a_t[4];
-  bool a_ok[4], b_ok[4];
-  const float* wrow[4];
+  const float* wptr[4];
+  const float* aptr[4];
   const int ktot = p.taps * p.cin_pad;
   const float* W = static_cast<const float*>(p.w);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + r0 + 32 * i;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
-    const int seg = (mm / p.T) * p.T;
+    int m = m0 + r0 + 32 * i;
+    m = m < p.M ? m : p.M - 1;
+    const int seg = (m / p.T) * p.T;
     a_seg[i] = seg;
-    a_t[i] = mm - seg;
-    const int n = n0 + r0 + 32 * i;
-    b_ok[i] = n < p.cout;
-    wrow[i] = W + (size_t)(b_ok[i] ? n : 0) * ktot + c4 * 4;
+    a_t[i] = m - seg;
+    int n = n0 + r0 + 32 * i;
+    n = n < p.cout ? n : p.cout - 1;
+    wptr[i] = W + (size_t)n * ktot + c4 * 4;
   }
-  const int kpt = p.cin_pad / BK;
-  const int nk = p.taps * kpt;
+  const int nk = p.taps * (p.cin_pad / BK);
   const int half = p.taps / 2;
   const float* X = p.x + p.a_col0;
 
-  f32x4 ra[4], rb[4];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-  auto gload = [&](int kt) {
-    const int tap = kt / kpt;
-    const int c0 = (kt - tap * kpt) * BK + c4 * 4;
+  auto set_tap = [&](int tap) {
     const int delta = (tap - half) * p.dil;
-    const bool cok = c0 < p.cin;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int tt = a_t[i] + delta;
       tt = tt < 0 ? -tt : tt;
       tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
-      ra[i] = (a_ok[i] && cok)
-                  ? *reinterpret_cast<const f32x4*>(X + (size_t)(a_seg[i] + tt) * p.lda + c0)
-                  : zero4;
-      rb[i] = b_ok[i] ? *reinterpret_cast<const f32x4*>(wrow[i] + kt * BK) : zero4;
+      aptr[i] = X + (size_t)(a_seg[i] + tt) * p.lda;
+    }
+  };
+
+  f32x4 ra[4], rb[4];
+  int ld_tap = 0, ld_c0 = 0;  // position of the next K step to fetch
+  set_tap(0);
+  auto gload = [&]() {
+    const int col = ld_c0 + c4 * 4;
+    const int acol = col < p.cin ? col : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const f32x4*>(aptr[i] + acol);
+      rb[i] = *reinterpret_cast<const f32x4*>(wptr[i]);
+      wptr[i] += BK;
+    }
+    ld_c0 += BK;
+    if (ld_c0 >= p.cin_pad) {
+      ld_c0 = 0;
+      ++ld_tap;
+      if (ld_tap < p.taps) set_tap(ld_tap);
     }
   };
   auto lstore = [&](int buf) {
@@ -116,62 +130,117 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
 
-  gload(0);
+  struct Frag { f32x4 a0, a1, b0, b1; };
+  auto fread = [&](const float* a, const float* b, int k8) {
+    Frag f;
+    f.a0 = *reinterpret_cast<const f32x4*>(a + k8 * 8);
+    f.a1 = *reinterpret_cast<const f32x4*>(a + 32 * LDP + k8 * 8);
+    f.b0 = *reinterpret_cast<const f32x4*>(b + k8 * 8);
+    f.b1 = *reinterpret_cast<const f32x4*>(b + 32 * LDP + k8 * 8);
+    return f;
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[r], f.b0[r], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[r], f.b1[r], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[r], f.b0[r], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[r], f.b1[r], acc[1][1], 0, 0, 0);
+    }
+  };
+
+  gload();
   lstore(0);
   __syncthreads();
 
+  // One barrier per K step.  The fetch of step kt+1 is issued behind the first MFMA group
+  // and written to the other LDS stage ahead of the last group, so the part of a K step in
+  // which this wave issues no MFMA is as short as possible (its SIMD partner from the other
+  // resident workgroup runs the same program and tends to fall into phase with it).
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more) gload(kt + 1);
-
     const float* a = As + cur * BM * LDP + (wm * 64 + frag_row) * LDP + frag_k;
     const float* b = Bs + cur * BN * LDP + (wn * 64 + frag_row) * LDP + frag_k;
-#pragma unroll
-    for (int k8 = 0; k8 < BK / 8; ++k8) {
-      f32x4 fa[2], fb[2];
-      fa[0] = *reinterpret_cast<const f32x4*>(a + k8 * 8);
-      fa[1] = *reinterpret_cast<const f32x4*>(a + 32 * LDP + k8 * 8);
-      fb[0] = *reinterpret_cast<const f32x4*>(b + k8 * 8);
-      fb[1] = *reinterpret_cast<const f32x4*>(b + 32 * LDP + k8 * 8);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][r], fb[0][r], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][r], fb[1][r], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][r], fb[0][r], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][r], fb[1][r], acc[1][1], 0, 0, 0);
-      }
-    }
-
+    Frag f0 = fread(a, b, 0);
+    Frag f1 = fread(a, b, 1);
+    mma(f0);
+    if (more) gload();
+    f0 = fread(a, b, 2);
+    mma(f1);
+    f1 = fread(a, b, 3);
+    mma(f0);
     if (more) lstore(cur ^ 1);
+    mma(f1);
     __syncthreads();
     cur ^= 1;
   }
 
-  // ---- epilogue: lane owns column n, 16 rows per MFMA tile
+  // ---- epilogue, phase 1: bias / activation / BN affine on the accumulators (lane owns
+  // column n, 16 rows per MFMA tile), result staged in LDS as a [BM][LDC] tile.  The main
+  // loop's last barrier has retired every read of As/Bs, so the stage can be reused.
+  float* Cs = smem;
   const int hrow = (lane >> 5) * 4;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
-    const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
-    if (n >= p.cout) continue;
-    const float bias_n = (p.bias && !p.bias_per_seg) ? p.bias[n] : 0.f;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float sh = p.shift ? p.shift[n] : 0.f;
-    const bool tee_n = p.tee && n >= p.tee_lo && n < p.tee_hi;
+    const int cl = wn * 64 + ni * 32 + (lane & 31);
+    const int n = n0 + cl;
+    const bool nok = n < p.cout;
+    const float bias_n = (nok && p.bias && !p.bias_per_seg) ? p.bias[n] : 0.f;
+    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
+    const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-        if (m >= p.M) continue;
+        const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + hrow;
         float v = acc[mi][ni][r];
-        if (p.bias_per_seg) v += p.bias[(size_t)(m / p.T) * p.cout + n];
-        else v += bias_n;
+        if (p.bias_per_seg) {
+          const int m = m0 + rl;
+          v += (nok && m < p.M) ? p.bias[(size_t)(m / p.T) * p.cout + n] : 0.f;
+        } else {
+          v += bias_n;
+        }
         v = apply_act(v, p.act);
         v = v * sc + sh;
         v = apply_act(v, p.act2);
+        Cs[rl * LDC + cl] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: row-contiguous stores, 16 bytes per lane (a half-wave writes one 512-byte
+  // tile row), plus the optional tee  y (+ tee_add)  for the Res2Net chain.
+  const int cq = (tid & 31) * 4;   // tile column of this thread's float4
+  const int n4 = n0 + cq;
+  if (vec) {
+    if (n4 < p.cout) {
+      const bool tee_q = p.tee && n4 >= p.tee_lo && n4 < p.tee_hi;
+#pragma unroll 4
+      for (int rr = tid >> 5; rr < BM; rr += 8) {
+        const int m = m0 + rr;
+        if (m >= p.M) break;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cq);
+        *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldo + p.o_col0 + n4) = v;
+        if (tee_q) {
+          f32x4 tv = v;
+          if (p.tee_add) tv += *reinterpret_cast<const f32x4*>(p.tee_add + (size_t)m * p.ld_ta + p.ta_col0 + (n4 - p.tee_lo));
+          *reinterpret_cast<f32x4*>(p.tee + (size_t)m * p.ldt + (n4 - p.tee_lo)) = tv;
+        }
+      }
+    }
+  } else {
+    for (int rr = tid >> 5; rr < BM; rr += 8) {
+      const int m = m0 + rr;
+      if (m >= p.M) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n4 + e;
+        if (n >= p.cout) break;
+        const float v = Cs[rr * LDC + cq + e];
         p.y[(size_t)m * p.ldo + p.o_col0 + n] = v;
-        if (tee_n) {
+        if (p.tee && n >= p.tee_lo && n < p.tee_hi) {
           float tv = v;
           if (p.tee_add) tv += p.tee_add[(size_t)m * p.ld_ta + p.ta_col0 + (n - p.tee_lo)];
           p.tee[(size_t)m * p.ldt + (n - p.tee_lo)] = tv;
@@ -204,6 +273,12 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
     if (a->tee_add)
       SD_CHECK_ARG(a->ta_col0 >= 0 && a->ta_col0 + (a->tee_hi - a->tee_lo) <= a->ld_ta, "sd_conv1d_cl_f32: tee_add slice outside row");
   }
+  // 16-byte epilogue stores need every touched row slice 16-byte aligned
+  int vec = a->cout % 4 == 0 && a->ldo % 4 == 0 && a->o_col0 % 4 == 0 && sd_aligned16(a->y);
+  if (a->tee) {
+    vec = vec && a->tee_lo % 4 == 0 && a->tee_hi % 4 == 0 && a->ldt % 4 == 0 && sd_aligned16(a->tee);
+    if (a->tee_add) vec = vec && a->ld_ta % 4 == 0 && a->ta_col0 % 4 == 0 && sd_aligned16(a->tee_add);
+  }
   const long tiles_m = (a->M + BM - 1) / BM;
   const long tiles_n = (a->cout + BN - 1) / BN;
   SD_CHECK_ARG(tiles_m * tiles_n < (1L << 31), "sd_conv1d_cl_f32: grid too large");
@@ -218,7 +293,7 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
     SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream),
                      2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
     hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds,
-                       static_cast<hipStream_t>(stream), *a);
+                       static_cast<hipStream_t>(stream), *a, vec);
   }
   SD_CHECK_LAUNCH("conv_gemm_f32_kernel");
   return SD_OK;
