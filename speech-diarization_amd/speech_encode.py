@@ -1,0 +1,150 @@
+"""Feature + embedding front door — drop-in for the reference's `speech_encode.py`.
+
+Same callables, same array conventions (numpy in, fresh numpy out, `assert wavs.ndim == 2`):
+
+* `fbank_batch(wavs, sr, n_mels, mean_nor)`          [REF speech_encode.py:10-38]
+* `using_ecapa_encoder(device)` (lru_cache singleton)  [REF speech_encode.py:64-70]
+* `ecapa_encode_batch(wavs)`                           [REF speech_encode.py:73-78]
+* `using_eres2netv2_encoder()` / `eres2netv2_encode_batch(...)` [REF speech_encode.py:42-60]
+
+Behind them: the HIP fbank kernel and the HIP ECAPA-TDNN forward (libsd_hip.so).  Tables
+and weights are uploaded once per process, not per call, and a batch crosses PCIe once in
+each direction (the reference rebuilds its transform per call and crosses three times).
+There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from functools import lru_cache
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import EMBEDDING_DIM
+from .engine import EmbeddingEngine, fbank_device
+from .features import FbankPlan
+
+_THIS_DIR = Path(__file__).parent.resolve()
+ECAPA_SOURCE = "LanceaKing/spkrec-ecapa-cnceleb"  # [REF speech_encode.py:67]
+SYNTHETIC_SEED = 1234
+
+
+def _cuda_device(device) -> torch.device:
+    if isinstance(device, int):
+        return torch.device("cuda", device)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"the HIP embedding path runs on the GPU; device={device!r} is not supported (no CPU fallback)")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+@lru_cache(maxsize=4)
+def _fbank_plan(kind: str, n_mels: int, sr: int, device_index: int) -> FbankPlan:
+    with torch.cuda.device(device_index):
+        return FbankPlan(kind, n_mels=n_mels, sr=sr)
+
+
+def fbank_batch(wavs: np.ndarray,  # [B, n_samples]
+                sr: int = 16000, n_mels: int = 80, mean_nor: bool = True) -> np.ndarray:
+    """log-mel filterbank [B, T, n_mels]: 25 ms / 10 ms, 20 Hz .. sr/2-100 Hz, ln(x + 1e-6),
+    per-utterance mean removal when `mean_nor`."""
+    assert wavs.ndim == 2
+    if not torch.cuda.is_available():
+        raise RuntimeError("fbank_batch needs a GPU (the reference hard-codes 'cuda' too, [REF speech_encode.py:26,29])")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    plan = _fbank_plan("torchaudio", n_mels, sr, dev.index)
+    with torch.inference_mode():
+        x = torch.from_numpy(np.ascontiguousarray(wavs, dtype=np.float32)).to(dev)
+        feat = fbank_device(x, plan, mean_norm=mean_nor)
+    return feat.cpu().numpy()  # [B, T, n_mels]
+
+
+def _find_checkpoint() -> Path | None:
+    env = os.environ.get("SD_ECAPA_CKPT")
+    if env:
+        p = Path(env)
+        if not p.exists():
+            raise FileNotFoundError(f"SD_ECAPA_CKPT={env} does not exist")
+        return p
+    for cand in (_THIS_DIR / "models" / "spkrec-ecapa-cnceleb" / "embedding_model.ckpt",
+                 _THIS_DIR.parent / "models" / "spkrec-ecapa-cnceleb" / "embedding_model.ckpt"):
+        if cand.exists():
+            return cand
+    return None
+
+
+def load_ecapa_state_dict(path: str | os.PathLike | None = None) -> dict:
+    """speechbrain `embedding_model.ckpt` state dict if one is available locally, else
+    deterministic random-init weights of the same architecture (no network here)."""
+    ckpt = Path(path) if path is not None else _find_checkpoint()
+    if ckpt is not None:
+        sd = torch.load(ckpt, map_location="cpu", weights_only=True)
+        return {k: v.float().numpy() for k, v in sd.items() if torch.is_tensor(v) and v.dtype.is_floating_point}
+    from .synth import make_ecapa_state_dict
+    warnings.warn(
+        f"no local ECAPA checkpoint ({ECAPA_SOURCE} cannot be downloaded offline; set SD_ECAPA_CKPT): "
+        f"using random-init weights (seed {SYNTHETIC_SEED}) — embeddings carry no trained speaker information",
+        RuntimeWarning, stacklevel=2)
+    return make_ecapa_state_dict(SYNTHETIC_SEED)
+
+
+class HipEcapaEncoder:
+    """Stands in for speechbrain's `EncoderClassifier`: `.encode_batch(wavs) -> Tensor[B, 1, 192]`."""
+
+    def __init__(self, state_dict: dict, device, max_batch: int = 512):
+        self.device = _cuda_device(device)
+        self.engine = EmbeddingEngine(state_dict, self.device, max_batch=max_batch)
+        self.embedding_dim = self.engine.dim
+
+    @torch.inference_mode()
+    def encode_batch(self, wavs: torch.Tensor, wav_lens: torch.Tensor | None = None, normalize: bool = False) -> torch.Tensor:
+        if wavs.dim() == 1:
+            wavs = wavs.unsqueeze(0)
+        if wav_lens is not None and not bool(torch.all(wav_lens == 1)):
+            raise NotImplementedError("relative lengths are not supported: the reference never passes wav_lens, "
+                                      "zero-padded tails count as signal [REF anti_stick_diarize.py:163-168]")
+        if normalize:
+            raise NotImplementedError("normalize=True (speechbrain mean_var_norm_emb) is not used by the reference")
+        x = wavs.to(self.device, dtype=torch.float32, non_blocking=True)
+        return self.engine.embed(x).unsqueeze(1)
+
+    __call__ = encode_batch
+
+
+@lru_cache(maxsize=1)
+def using_ecapa_encoder(device: str | int = "cuda") -> HipEcapaEncoder:
+    if not torch.cuda.is_available():
+        raise RuntimeError("using_ecapa_encoder: no GPU visible; the HIP path has no CPU fallback")
+    return HipEcapaEncoder(load_ecapa_state_dict(), device)
+
+
+def ecapa_encode_batch(wavs: np.ndarray) -> np.ndarray:
+    encoder = using_ecapa_encoder()
+    with torch.inference_mode():
+        x = torch.from_numpy(np.ascontiguousarray(wavs)).float()
+        y = encoder.encode_batch(x).squeeze(1).cpu().numpy()
+    return y  # [B, 192]
+
+
+@lru_cache(maxsize=1)
+def using_eres2netv2_encoder():
+    """The reference opens an ONNX file that is git-ignored and absent [REF speech_encode.py:42-50];
+    the ERes2NetV2 network is outside this hot path (north_star names ECAPA)."""
+    onnx_path = _THIS_DIR / "models/iic-speech_eres2netv2w24s4ep4_sv_zh-cn_16k-common.onnx"
+    raise FileNotFoundError(
+        f"{onnx_path}: the ERes2NetV2 ONNX model is not shipped and onnxruntime is not part of the MI355X path; "
+        "use using_ecapa_encoder() / ecapa_encode_batch()")
+
+
+def eres2netv2_encode_batch(wavs: np.ndarray, sr: int = 16000, num_mels: int = 80) -> np.ndarray:
+    assert wavs.ndim == 2
+    session = using_eres2netv2_encoder()
+    features = fbank_batch(wavs, sr=sr, n_mels=num_mels, mean_nor=True)
+    return session.run(None, dict(feature=features))[0]  # [B, 192]
+
+
+assert EMBEDDING_DIM == 192

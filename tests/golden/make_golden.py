@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own glue functions.
+
+    python -B tests/golden/make_golden.py          # only works where /root/reference exists
+
+The reference's flat modules import third-party packages that are not installed
+(numba, librosa, onnxruntime, pyloudnorm, hdbscan, torchaudio, speechbrain, dacite,
+pyannote).  They are replaced by INERT stubs (no behaviour: anything called on them raises),
+which is enough to import the modules and execute the pure-numpy / pure-python functions the
+reference itself authored.  Two call-throughs are substituted with test doubles, and the
+fixtures say so: `ecapa_encode_batch` (a deterministic, row-independent stand-in encoder
+defined below — the real one needs downloaded weights) and `frame_audio` (librosa.util.frame
+is absent; the framing n = 1 + (len - win) // hop is restated in our `vad.frame_audio`).
+What is pinned is therefore the reference's batching / padding / merging / thresholding logic.
+
+Only inputs and outputs (small JSON) are written to tests/golden/; no reference source is copied.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+class _Inert(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        def _raise(*a, **k):
+            raise RuntimeError(f"stub {self.__name__}.{name} called: this dependency is absent")
+        return _raise
+
+
+def install_stubs():
+    import torch
+    names = ["numba", "librosa", "librosa.util", "librosa.effects", "onnxruntime", "pyloudnorm", "hdbscan", "torchaudio",
+             "torchaudio.transforms", "speechbrain", "speechbrain.inference", "speechbrain.inference.classifiers",
+             "dacite", "pyannote", "pyannote.audio", "pyannote.core", "pyannote.audio.core", "pyannote.audio.core.model",
+             "pyannote.audio.pipelines", "pyannote.audio.pipelines.utils", "pyannote.audio.pipelines.utils.hook",
+             "jsonargparse"]
+    for n in names:
+        sys.modules[n] = _Inert(n)
+    sys.modules["numba"].jit = lambda *a, **k: (lambda f: f)
+    sys.modules["pyannote.audio.core.model"].Model = type("Model", (torch.nn.Module,), {})
+    for mod, attrs in {"torchaudio.transforms": ["MelSpectrogram"], "speechbrain.inference.classifiers": ["EncoderClassifier"],
+                       "hdbscan": ["HDBSCAN"], "dacite": ["from_dict", "Config"], "pyannote.audio": ["Pipeline"],
+                       "pyannote.core": ["Annotation"], "pyannote.audio.pipelines.utils.hook": ["ProgressHook"]}.items():
+        for a in attrs:
+            setattr(sys.modules[mod], a, type(a, (), {}))
+
+
+def fake_encode(wavs: np.ndarray) -> np.ndarray:
+    """Deterministic, row-independent stand-in for ecapa_encode_batch: 192 band energies of the
+    row (zero padding lowers them, as it would change a real embedding)."""
+    wavs = np.asarray(wavs, dtype=np.float64)
+    n = wavs.shape[1]
+    edges = np.linspace(0, n, 193).astype(int)
+    out = np.stack([np.abs(wavs[:, edges[d]:max(edges[d + 1], edges[d] + 1)]).mean(axis=1) * (1.0 + 0.01 * d)
+                    for d in range(192)], axis=1)
+    return (out + 0.05 * np.sin(np.arange(192))[None, :]).astype(np.float32)
+
+
+def test_signal(seed: int, seconds: float, sr: int = 16000) -> np.ndarray:
+    """Piecewise-stationary signal: the carrier and envelope change every few seconds."""
+    from speech_diarization_amd import synth
+    n = int(seconds * sr)
+    t = np.arange(n) / sr
+    u = synth.uniform(seed, "golden.sig", (64,))
+    y = np.zeros(n)
+    pos, k = 0.0, 0
+    while pos < seconds:
+        dur = 1.5 + 3.0 * float(u[k % 64]); f = 100.0 + 700.0 * float(u[(k + 7) % 64]); amp = 0.1 + 0.5 * float(u[(k + 13) % 64])
+        a, b = int(pos * sr), min(n, int((pos + dur) * sr))
+        y[a:b] = amp * np.sin(2 * np.pi * f * t[a:b]) * (1.0 + 0.5 * np.sin(2 * np.pi * (2 + k % 3) * t[a:b]))
+        pos += dur; k += 1
+    return y.astype(np.float32)
+
+
+def jsonable(x):
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    if isinstance(x, (np.floating, np.integer, np.bool_)):
+        return x.item()
+    if isinstance(x, (list, tuple)):
+        return [jsonable(v) for v in x]
+    if isinstance(x, dict):
+        return {k: jsonable(v) for k, v in x.items()}
+    return x
+
+
+def main():
+    install_stubs()
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    import vad as rvad
+    import anti_stick_diarize as rasd
+    import diarization_baseline as rdb
+    from speech_diarization_amd import synth
+    from speech_diarization_amd import vad as myvad
+
+    out = {}
+
+    # ---- VAD post-processing on synthetic probability tracks (masks stored as '0'/'1' strings)
+    def bits(m):
+        return "".join("1" if v else "0" for v in np.asarray(m).astype(bool))
+
+    tracks = []
+    inputs = []
+    for seed, n in [(1, 94), (2, 400), (3, 1000), (4, 37), (5, 2000), (6, 1)]:
+        u = synth.uniform(seed, "golden.vad", (n,))
+        t = np.arange(n)
+        probs = np.clip(0.5 + 0.45 * np.sin(t / (5.0 + seed)) * np.sign(np.sin(t / (31.0 + 3 * seed))) + 0.25 * (u - 0.5), 0, 1)
+        inputs.append(np.round(probs, 4).astype(np.float32))
+    inputs.append(np.zeros(50, np.float32))
+    inputs.append(np.ones(50, np.float32))
+    for probs in inputs:
+        variants = []
+        for on, off in [(0.6, 0.4), (0.5, 0.5), (0.7, 0.2)]:
+            mask = rvad.hysteresis_binarize(probs, on, off)
+            morphs = []
+            for open_ms, close_ms in [(80.0, 40.0), (0.0, 40.0), (30.0, 0.0)]:
+                m2 = rvad.morph_open_close(mask, 10.0, open_ms, close_ms)
+                segs = []
+                for min_speech, min_gap, pad in [(250.0, 100.0, 80.0), (250.0, 100.0, 40.0), (150.0, 250.0, 0.0), (25.0, 5.0, 15.0)]:
+                    segs.append(dict(min_speech_ms=min_speech, min_gap_ms=min_gap, speech_pad_ms=pad,
+                                     segments=rvad.mask_to_segments(m2, 10.0, min_speech, min_gap, pad)))
+                morphs.append(dict(open_ms=open_ms, close_ms=close_ms, mask=bits(m2), segments=segs))
+            variants.append(dict(on=on, off=off, hyst=bits(mask), morphs=morphs))
+        tracks.append(dict(probs=[float(v) for v in probs], variants=variants))
+    out["vad"] = tracks
+
+    # ---- diarization_baseline glue
+    db = []
+    for seed in range(12):
+        u = synth.uniform(seed, "golden.db", (40,))
+        t, segs = 0.0, []
+        for i in range(13):
+            t += float(u[3 * i]) * 2.0
+            d = 0.2 + float(u[3 * i + 1]) * 9.0
+            spk = ["A", "B", "C"][int(u[3 * i + 2] * 3) % 3] if seed % 2 else int(u[3 * i + 2] * 3) % 3
+            segs.append((round(t, 3), round(t + d, 3), spk))
+            t += d - (0.3 if i % 5 == 4 else 0.0)   # occasional overlap
+        for gap, mx in [(1.2, 20.0), (1.0, 20.0), (0.3, 5.0)]:
+            merged = rdb.merge_same_speaker(list(segs), gap, mx)
+            for padv in [0.04, 0.06, 0.5]:
+                db.append(dict(segments=segs, max_gap_s=gap, max_segment_s=mx, merged=merged, padding=padv,
+                               adjusted=rdb.adjust_segment_boundaries(list(merged), padv)))
+    db.append(dict(segments=[], max_gap_s=1.2, max_segment_s=20.0, merged=rdb.merge_same_speaker([], 1.2, 20.0), padding=0.04,
+                   adjusted=rdb.adjust_segment_boundaries([], 0.04)))
+    out["diarization_baseline"] = db
+    p = rdb.DiarizationParameters()
+    out["diarization_parameters"] = {k: getattr(p, k) for k in p.__dataclass_fields__}
+
+    # ---- anti_stick_diarize glue with the stand-in encoder
+    rasd.ecapa_encode_batch = fake_encode
+    rasd.frame_audio = myvad.frame_audio
+    rasd.track = lambda it, **k: it          # silence rich progress bars
+    asd = []
+    for seed, seconds in [(11, 24.0), (12, 40.0)]:
+        y = test_signal(seed, seconds)
+        sr = 16000
+        u = synth.uniform(seed, "golden.asd", (64,))
+        t, segs = 0.2, []
+        k = 0
+        while t < seconds - 1.0:
+            d = [0.3, 0.45, 1.2, 2.5, 5.0, 7.5][int(u[k % 64] * 6) % 6]
+            e = min(seconds - 0.05, t + d)
+            segs.append((round(t, 3), round(e, 3)))
+            t = e + 0.05 + float(u[(k + 1) % 64]) * 0.8
+            k += 2
+        calls = []
+
+        def logging_encode(w, _calls=calls):
+            _calls.append([int(w.shape[0]), int(w.shape[1]), float(np.abs(w).sum())])
+            return fake_encode(w)
+
+        rasd.ecapa_encode_batch = logging_encode
+        embs = rasd.embed_segments(y, sr, [rasd.Segment(s, e) for s, e in segs])
+        embed_calls = list(calls)
+        calls.clear()
+        long_segs = [rasd.Segment(s, e) for s, e in segs if e - s >= 1.0]
+        scd = {}
+        for thr in (0.5, 1.25):
+            res = rasd.scd_split_segments(y, sr, [rasd.Segment(s.start, s.end) for s in long_segs], thr=thr)
+            scd[str(thr)] = [(s.start, s.end) for s in res]
+        rasd.ecapa_encode_batch = fake_encode
+        labels = [int(u[(3 * i) % 64] * 3) % 3 for i in range(len(segs))]
+        labelled = [rasd.Segment(s, e, lab) for (s, e), lab in zip(segs, labels)]
+        merged = rasd.conservative_merge([rasd.Segment(s.start, s.end, s.spk) for s in labelled], embs, 0.5, 30.0, 0.80)
+        merged_loose = rasd.conservative_merge([rasd.Segment(s.start, s.end, s.spk) for s in labelled], embs, 1.0, 10.0, 0.0)
+        merged_bug = rasd.conservative_merge([rasd.Segment(s.start, s.end, s.spk) for s in labelled], np.asarray(labels), 0.5, 30.0, 0.80)
+        _, cents = rasd.speaker_centroids(labelled, embs)
+        starts, valid = rasd._get_speech_windows(y, sr, [rasd.Segment(s, e) for s, e in segs], 16000, 1600)
+        wl = np.asarray([int(u[i % 64] * 3) % 3 for i in range(len(valid))])
+        l2s = rasd._labels_to_segments(starts, valid, wl, sr, len(y) / sr)
+        adj = rasd.merge_adjacent([rasd.Segment(s.start, s.end, s.spk) for s in l2s], gap=0.05)
+        asd.append(dict(seed=seed, seconds=seconds, segments=segs, labels=labels, embed_calls=embed_calls,
+                        embs_sum=float(np.abs(embs).sum()), embs_first=embs[0][:8], embs_last=embs[-1][:8], scd=scd,
+                        merged=[(s.start, s.end, s.spk) for s in merged], merged_loose=[(s.start, s.end, s.spk) for s in merged_loose],
+                        merged_labels_as_embs=[(s.start, s.end, s.spk) for s in merged_bug], centroids_head=cents[:, :6],
+                        n_windows=len(starts), valid=valid, window_labels=wl, labels_to_segments=[(s.start, s.end, s.spk) for s in l2s],
+                        merge_adjacent=[(s.start, s.end, s.spk) for s in adj]))
+    out["anti_stick_diarize"] = asd
+
+    for name, payload in out.items():
+        with open(os.path.join(HERE, f"{name}.json"), "w") as f:
+            json.dump(jsonable(payload), f)
+        print(name, os.path.getsize(os.path.join(HERE, f"{name}.json")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+"""Host-side glue against golden vectors produced by the REFERENCE's own functions
+(tests/golden/make_golden.py imports /root/reference with inert stubs and records outputs)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from speech_diarization_amd import anti_stick_diarize as asd
+from speech_diarization_amd import diarization_baseline as db
+from speech_diarization_amd import vad
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, f"{name}.json")) as f:
+        return json.load(f)
+
+
+def _bits(s):
+    return np.frombuffer(s.encode(), dtype=np.uint8) == ord("1")
+
+
+def _pairs(x):
+    return [tuple(v) for v in x]
+
+
+def test_vad_postprocessing_matches_reference(golden_dir):
+    tracks = _load(golden_dir, "vad")
+    n_cases = 0
+    for tr in tracks:
+        probs = np.asarray(tr["probs"], dtype=np.float32)
+        for var in tr["variants"]:
+            mask = vad.hysteresis_binarize(probs, var["on"], var["off"])
+            assert mask.dtype == np.bool_
+            assert np.array_equal(mask, _bits(var["hyst"])), (var["on"], var["off"])
+            for mo in var["morphs"]:
+                m2 = vad.morph_open_close(mask, 10.0, mo["open_ms"], mo["close_ms"])
+                assert np.array_equal(m2, _bits(mo["mask"]))
+                for sg in mo["segments"]:
+                    got = vad.mask_to_segments(m2, 10.0, sg["min_speech_ms"], sg["min_gap_ms"], sg["speech_pad_ms"])
+                    assert got == _pairs(sg["segments"])
+                    assert all(isinstance(a, float) and isinstance(b, float) for a, b in got)
+                    n_cases += 1
+    assert n_cases >= 200
+
+
+def test_vad_edge_cases():
+    assert vad.mask_to_segments(np.zeros(10, bool), 10.0) == []
+    assert vad.mask_to_segments(np.zeros(0, bool), 10.0) == []
+    assert vad.hysteresis_binarize(np.zeros(0, np.float32)).shape == (0,)
+    # banker's rounding of the frame counts: round(25 / 10) == 2, so a 2-frame run survives min_speech_ms=25
+    m = np.zeros(20, bool); m[5:7] = True
+    assert vad.mask_to_segments(m, 10.0, min_speech_ms=25.0, min_gap_ms=0.0, speech_pad_ms=0.0) == [(0.05, 0.07)]
+    # filter-then-merge: two short runs separated by a tiny gap are both dropped, not merged
+    m = np.zeros(100, bool); m[10:20] = True; m[22:32] = True
+    assert vad.mask_to_segments(m, 10.0, min_speech_ms=250.0, min_gap_ms=100.0, speech_pad_ms=0.0) == []
+
+
+def test_frame_audio_shape_and_errors():
+    y = np.arange(16000, dtype=np.float32)
+    f = vad.frame_audio(y, 16000, 30.0, 10.0)
+    assert f.shape == (1 + (16000 - 480) // 160, 480)
+    assert np.array_equal(f[3], y[480:960])
+    assert vad.frame_audio(y, 16000, 1000.0, 200.0).shape == (1, 16000)
+    with pytest.raises(ValueError):
+        vad.frame_audio(y[:100], 16000, 30.0, 10.0)
+
+
+def test_silero_needs_a_scorer_offline():
+    with pytest.raises(RuntimeError, match="torch.hub"):
+        vad.SileroVAD()
+    p = vad.SileroVAD(model=vad.EnergyScorer()).probs(np.zeros(16000, np.float32), batch_size=7)
+    assert p.shape == (98,) and p.dtype == np.float32 and p.max() < 0.5
+
+
+def test_merge_same_speaker_and_boundaries_match_reference(golden_dir):
+    for case in _load(golden_dir, "diarization_baseline"):
+        segs = _pairs(case["segments"])
+        merged = db.merge_same_speaker(list(segs), case["max_gap_s"], case["max_segment_s"])
+        assert merged == _pairs(case["merged"])
+        assert db.adjust_segment_boundaries(list(merged), case["padding"]) == _pairs(case["adjusted"])
+
+
+def test_diarization_parameters_defaults_match_reference(golden_dir):
+    ref = _load(golden_dir, "diarization_parameters")
+    p = db.DiarizationParameters()
+    assert {k: getattr(p, k) for k in p.__dataclass_fields__} == ref
+    with pytest.raises(Exception):
+        p.min_speakers = 3          # frozen, like the reference's dataclass
+
+
+def _fake_encode(wavs):
+    """The stand-in encoder of tests/golden/make_golden.py (kept in sync by this test's fixtures)."""
+    wavs = np.asarray(wavs, dtype=np.float64)
+    n = wavs.shape[1]
+    edges = np.linspace(0, n, 193).astype(int)
+    out = np.stack([np.abs(wavs[:, edges[d]:max(edges[d + 1], edges[d] + 1)]).mean(axis=1) * (1.0 + 0.01 * d)
+                    for d in range(192)], axis=1)
+    return (out + 0.05 * np.sin(np.arange(192))[None, :]).astype(np.float32)
+
+
+def _signal(seed, seconds):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.test_signal(seed, seconds)
+
+
+def _triples(segs):
+    return [(s.start, s.end, s.spk) for s in segs]
+
+
+def test_embedding_callers_match_reference(golden_dir):
+    for case in _load(golden_dir, "anti_stick_diarize"):
+        y = _signal(case["seed"], case["seconds"])
+        sr = 16000
+        segs = _pairs(case["segments"])
+        calls = []
+
+        def enc(w):
+            calls.append([int(w.shape[0]), int(w.shape[1]), float(np.abs(w).sum())])
+            return _fake_encode(w)
+
+        embs = asd.embed_segments(y, sr, [asd.Segment(s, e) for s, e in segs], encode=enc)
+        # identical batch shapes AND contents (batches of 32, zero-padded to the batch max, short ones widened)
+        assert [c[:2] for c in calls] == [c[:2] for c in case["embed_calls"]]
+        assert np.allclose([c[2] for c in calls], [c[2] for c in case["embed_calls"]], rtol=1e-6)
+        assert embs.shape == (len(segs), 192) and embs.dtype == np.float32
+        assert np.isclose(np.abs(embs).sum(), case["embs_sum"], rtol=1e-6)
+        assert np.allclose(embs[0][:8], case["embs_first"], rtol=1e-6) and np.allclose(embs[-1][:8], case["embs_last"], rtol=1e-6)
+
+        long_segs = [asd.Segment(s, e) for s, e in segs if e - s >= 1.0]
+        for thr, expect in case["scd"].items():
+            res = asd.scd_split_segments(y, sr, [asd.Segment(s.start, s.end) for s in long_segs], thr=float(thr), encode=_fake_encode)
+            assert [(s.start, s.end) for s in res] == _pairs(expect)
+
+        labelled = [asd.Segment(s, e, lab) for (s, e), lab in zip(segs, case["labels"])]
+        fresh = lambda: [asd.Segment(s.start, s.end, s.spk) for s in labelled]   # noqa: E731
+        assert _triples(asd.conservative_merge(fresh(), embs, 0.5, 30.0, 0.80)) == _pairs(case["merged"])
+        assert _triples(asd.conservative_merge(fresh(), embs, 1.0, 10.0, 0.0)) == _pairs(case["merged_loose"])
+        assert _triples(asd.conservative_merge(fresh(), np.asarray(case["labels"]), 0.5, 30.0, 0.80)) == _pairs(case["merged_labels_as_embs"])
+        ids, cents = asd.speaker_centroids(labelled, embs)
+        assert ids.tolist() == sorted(set(case["labels"]))
+        assert np.allclose(cents[:, :6], case["centroids_head"], rtol=1e-5)
+
+        starts, valid = asd._get_speech_windows(y, sr, [asd.Segment(s, e) for s, e in segs], 16000, 1600)
+        assert len(starts) == case["n_windows"] and valid.tolist() == case["valid"]
+        l2s = asd._labels_to_segments(starts, valid, np.asarray(case["window_labels"]), sr, len(y) / sr)
+        assert _triples(l2s) == _pairs(case["labels_to_segments"])
+        assert _triples(asd.merge_adjacent(l2s, gap=0.05)) == _pairs(case["merge_adjacent"])
+
+
+def test_embedding_callers_edge_cases():
+    y = np.zeros(16000, np.float32)
+    assert asd.embed_segments(y, 16000, [], encode=_fake_encode).shape == (0, 192)
+    assert asd.conservative_merge([], np.zeros((0, 192))) == []
+    assert asd.merge_adjacent([]) == []
+    ids, c = asd.speaker_centroids([asd.Segment(0, 1, -1)], np.ones((1, 192), np.float32))
+    assert ids.shape == (0,) and c.shape == (0, 192)
+    # fewer than 3 SCD windows -> the segment is kept whole [REF anti_stick_diarize.py:96-98]
+    seg = [asd.Segment(0.0, 1.3)]
+    assert asd.scd_split_segments(np.zeros(32000, np.float32), 16000, seg, encode=_fake_encode) == seg
+    assert asd.frame_reassign(y, 16000, [], [], np.zeros((0, 192)), encode=_fake_encode) == []

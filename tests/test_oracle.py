@@ -1,0 +1,99 @@
+"""The CPU oracle checked against itself and against what CAN be pinned in this container.
+
+fbank / ECAPA arithmetic lives in torchaudio / speechbrain, which are absent (parity unpinned,
+see oracle/__init__.py): each restatement is cross-checked against an independent formulation
+and against analytic known answers.  Cosine semantics are pinned live against scikit-learn.
+"""
+import numpy as np
+import torch
+
+from oracle import ecapa_ref, fbank_ref, pipeline_ref
+from speech_diarization_amd import features, synth
+
+
+def test_fbank_framed_dft_agrees_with_torch_stft():
+    wav = synth.synthetic_segments(5, 3, 8000)
+    a = fbank_ref.fbank_batch_ref(wav)
+    b = fbank_ref.fbank_batch_torch(torch.from_numpy(wav)).numpy()
+    assert a.shape == b.shape == (3, 51, 80)
+    assert np.abs(a - b).max() < 1e-4
+    c = fbank_ref.speechbrain_fbank_ref(wav)
+    d = fbank_ref.speechbrain_fbank_torch(torch.from_numpy(wav)).numpy()
+    assert np.abs(c - d).max() < 5e-4
+
+
+def test_fbank_known_answers():
+    z = fbank_ref.fbank_batch_ref(np.zeros((1, 4000), np.float32), mean_nor=False)
+    assert np.allclose(z, np.log(1e-6))
+    assert np.all(fbank_ref.fbank_batch_ref(np.zeros((1, 4000), np.float32)) == 0)
+    t = np.arange(16000) / 16000.0
+    tone = (0.5 * np.sin(2 * np.pi * 1000.0 * t))[None]
+    f = fbank_ref.fbank_batch_ref(tone, mean_nor=False)[0]
+    fb = fbank_ref.melscale_fbanks_htk(201, 20.0, 7900.0, 80, 16000)
+    assert abs(int(np.argmax(f[50])) - int(np.argmax(fb[25]))) <= 1
+    # top_db: nothing sits more than 80 dB under the utterance maximum
+    quiet = synth.synthetic_segments(1, 1, 16000)
+    quiet[0, 8000:] *= 1e-7
+    s = fbank_ref.speechbrain_fbank_ref(quiet, mean_norm=False)
+    assert s.max() - s.min() <= 80.0 + 1e-9
+    assert np.isclose(s.min(), s.max() - 80.0)
+
+
+def test_kernel_tables_agree_with_oracle_tables():
+    """The host tables fed to the HIP kernel vs the oracle's own restatement of the filter banks."""
+    assert np.allclose(features.mel_filters_torchaudio(), fbank_ref.melscale_fbanks_htk(201, 20.0, 7900.0, 80, 16000), atol=1e-7)
+    assert np.allclose(features.mel_filters_speechbrain(), fbank_ref.speechbrain_filterbank(201, 80, 16000), atol=1e-7)
+    for fb in (features.mel_filters_torchaudio(), features.mel_filters_speechbrain()):
+        assert (np.count_nonzero(fb, axis=1) <= 2).all()      # what the sparse mel table of the kernel relies on
+    for kind in ("hann", "hamming"):
+        w = features.periodic_window(kind)
+        assert np.array_equal(w[1:200], w[399:200:-1])        # w[k] == w[400-k]
+        assert np.allclose(w, fbank_ref._window(kind, 400), atol=1e-7)
+
+
+def test_ecapa_torch_and_numpy_formulations_agree():
+    sd = synth.make_ecapa_state_dict(7, synth.EcapaConfig.small(64))
+    feats = fbank_ref.speechbrain_fbank_ref(synth.synthetic_segments(0, 2, 8000))
+    a, inter = ecapa_ref.EcapaRef(sd, torch.float64).forward_features(torch.from_numpy(feats), return_intermediates=True)
+    b = ecapa_ref.ecapa_forward_numpy(sd, feats)
+    assert a.shape == (2, 192)
+    assert np.abs(a.numpy() - b).max() < 1e-10
+    assert inter["block1"].shape == (2, 64, 51) and inter["mfa"].shape == (2, 192, 51) and inter["pooled"].shape == (2, 384, 1)
+    f32 = ecapa_ref.EcapaRef(sd, torch.float32).forward_features(torch.from_numpy(feats)).numpy()
+    assert np.abs(f32 - b).max() < 1e-3 * np.abs(b).max()
+
+
+def test_ecapa_geometry_and_parameter_count():
+    """spkrec-ecapa geometry: 20.8 M parameters, 192-d output [REF ecapa_annote.py:11]."""
+    cfg = synth.EcapaConfig()
+    assert cfg.n_blocks == 3 and cfg.channels[-1] == 3072
+    small = synth.make_ecapa_state_dict(1, synth.EcapaConfig.small(64))
+    assert synth.config_from_state_dict(small) == synth.EcapaConfig.small(64)
+    # closed-form parameter count of the full geometry (weights + biases + BN affine), no allocation
+    c, k = 1024, 3
+    n = 80 * 5 * c + c + 2 * c
+    per_block = (c * c + c + 2 * c) * 2 + 7 * (128 * 128 * k + 128 + 2 * 128) + (c * 128 + 128) + (128 * c + c)
+    n += 3 * per_block + (3072 * 3072 + 3072 + 2 * 3072) + (9216 * 128 + 128 + 2 * 128) + (128 * 3072 + 3072) + 2 * 6144 + (6144 * 192 + 192)
+    assert 20.7e6 < n < 20.9e6
+
+
+def test_synthetic_weights_are_deterministic():
+    a = synth.make_ecapa_state_dict(3, synth.EcapaConfig.small(64))
+    b = synth.make_ecapa_state_dict(3, synth.EcapaConfig.small(64))
+    c = synth.make_ecapa_state_dict(4, synth.EcapaConfig.small(64))
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert not np.array_equal(a["fc.conv.weight"], c["fc.conv.weight"])
+    w = a["blocks.1.tdnn1.conv.conv.weight"]
+    assert abs(float(w.std()) - 1 / 8.0) < 0.01 and abs(float(w.mean())) < 0.01
+    x = synth.synthetic_segments(0, 4, 32000)
+    assert x.dtype == np.float32 and abs(float(x.std()) - 0.1) < 0.005 and np.abs(x).max() <= 1.0
+
+
+def test_cosine_reference_semantics():
+    x = np.random.default_rng(0).standard_normal((6, 192)).astype(np.float32)
+    x[2] = 0
+    k = pipeline_ref.cosine_similarity_ref(x)
+    assert k.dtype == np.float32                                   # dtype preserved
+    assert np.all(k[2] == 0) and np.all(k[:, 2] == 0)              # zero-norm row divided by 1
+    assert np.allclose(np.diag(k)[[0, 1, 3, 4, 5]], 1.0, atol=1e-6)
+    assert np.allclose(pipeline_ref.cosine_similarity_ref(np.eye(5, dtype=np.float32)), np.eye(5))

@@ -1,0 +1,81 @@
+"""BASELINE.json configs[0]: the diarization_baseline entry point on a 60 s 2-speaker synthetic WAV
+with a PyTorch-CPU ECAPA (the oracle, injected as `encoder=`) and spectral clustering — plumbing,
+no GPU.  Checks the output schema (segment tuples, RTTM lines), speaker count and turn boundaries.
+The GPU twin of this test (tests/test_gpu_pipeline.py) must produce the identical RTTM."""
+import numpy as np
+import pytest
+import torch
+
+from speech_diarization_amd import audio_io, diarization_baseline as db, rttm, synth
+
+
+@pytest.fixture(scope="module")
+def conversation(tmp_path_factory):
+    conv = synth.synthetic_conversation(60.0, n_speakers=2, seed=0)
+    path = tmp_path_factory.mktemp("cfg0") / "meeting.wav"
+    audio_io.write_wav16(path, conv.wav, conv.sr)
+    return conv, path
+
+
+def cpu_oracle_encoder(width=128, seed=1234):
+    from oracle.ecapa_ref import EcapaRef
+    from oracle.pipeline_ref import encode_batch_ref
+    sd = synth.make_ecapa_state_dict(seed, synth.EcapaConfig.small(width))
+    net = EcapaRef(sd, torch.float32)
+    return lambda wavs: encode_batch_ref(sd, np.asarray(wavs, np.float32), torch.float32, net).astype(np.float32)
+
+
+def test_config0_plumbing(conversation, tmp_path):
+    conv, path = conversation
+    out_rttm = tmp_path / "meeting.rttm"
+    segments, det = db.diarize_audio(path, 0.35, 0.1, 2, 6, rttm_filepath=out_rttm, encoder=cpu_oracle_encoder(),
+                                     clustering="spectral", return_details=True)
+    # schema: (start_s, end_s, "SPEAKER_xx") tuples, sorted, non-empty
+    assert segments and all(len(s) == 3 and isinstance(s[2], str) and s[2].startswith("SPEAKER_") and s[1] > s[0] for s in segments)
+    assert {s[2] for s in segments} == {"SPEAKER_00", "SPEAKER_01"}
+    lines = out_rttm.read_text().splitlines()
+    assert len(lines) == len(segments)
+    for ln, (s, e, k) in zip(lines, segments):
+        f = ln.split()
+        assert f[0] == "SPEAKER" and f[1] == "meeting" and f[2] == "1" and f[5:7] == ["<NA>", "<NA>"] and f[7] == k and f[8:] == ["<NA>", "<NA>"]
+        assert abs(float(f[3]) - s) < 1e-3 and abs(float(f[4]) - (e - s)) < 2e-3
+    assert rttm.read_rttm(out_rttm) == [(pytest.approx(s, abs=1e-3), pytest.approx(e, abs=2e-3), k) for s, e, k in segments]
+    # the two synthetic voices are recovered: DER against the ground-truth turns is small
+    truth = [(s, e, f"T{k}") for s, e, k in conv.turns]
+    assert rttm.der(truth, segments) < 0.10
+    # every true turn boundary has a hypothesis boundary within 0.25 s
+    hyp_edges = np.array([s for s, _, _ in segments] + [e for _, e, _ in segments])
+    for s, e, _ in conv.turns:
+        assert np.abs(hyp_edges - s).min() < 0.25 and np.abs(hyp_edges - e).min() < 0.25
+    assert det["embeddings"].shape[1] == 192 and len(det["labels"]) == det["embeddings"].shape[0]
+
+
+def test_diarizer_end_to_end_writes_stems(conversation, tmp_path):
+    conv, path = conversation
+    hp = db.DiarizationParameters(min_speakers=2, max_speakers=4, fade_ms=30.0, same_speaker_gap_s=1.0)
+    d = db.Diarizer(hp, encoder=cpu_oracle_encoder(64))
+    segments, info = d(path, tmp_path / "meeting-speakers", with_rttm=False)
+    assert len({k for _, _, k in segments}) == 2
+    assert set(info) == {k for _, _, k in segments}
+    for spk, files in info.items():
+        assert files and all(f.endswith(".wav") and f"/{spk}/meeting-" in f for f in files)
+        for f in files:
+            y, sr = audio_io.read_audio(f, 16000, mono=True)
+            assert 3.0 <= len(y) / sr <= hp.max_segment_s + 1e-6
+
+
+def test_segment_glue_units():
+    segs = [(0.0, 1.0, "A"), (1.5, 2.0, "A"), (4.0, 5.0, "A"), (5.1, 6.0, "B")]
+    assert db.merge_same_speaker(segs, 1.2, 20) == [(0.0, 2.0, "A"), (4.0, 5.0, "A"), (5.1, 6.0, "B")]
+    assert db.adjust_segment_boundaries([(0, 1, "A"), (1.5, 2, "A"), (2.01, 3, "B")], 0.04) == [(0, 1.04, "A"), (1.46, 2, "A"), (2.01, 3, "B")]
+    plans = db.plan_speaker_tracks([(0.0, 8.0, "A"), (9.0, 15.0, "A"), (30.0, 41.0, "A")], max_segment_s=20.0, max_gap_s=1.5)
+    assert plans["A"] == [[("speech", 0.0, 8.0), ("silence", 1.0), ("speech", 9.0, 15.0)], [("speech", 30.0, 41.0)]]
+    assert db.expand_audios.__name__ == "expand_audios"
+
+
+def test_der_scorer():
+    ref = [(0.0, 5.0, "a"), (5.0, 10.0, "b")]
+    assert rttm.der(ref, [(0.0, 5.0, "x"), (5.0, 10.0, "y")]) == 0.0          # label names do not matter
+    assert rttm.der(ref, [(0.0, 10.0, "x")]) == pytest.approx(0.5, abs=0.01)   # one speaker confused
+    assert rttm.der(ref, [(0.0, 5.0, "x")]) == pytest.approx(0.5, abs=0.01)    # half missed
+    assert rttm.der(ref, ref) == 0.0 and rttm.der([], []) == 0.0
