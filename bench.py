@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
 SAMPLES = 32000                # 2 s @ 16 kHz
 
@@ -42,6 +43,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--segments", type=int, default=10000, help="segments per rank per step")
     ap.add_argument("--micro-batch", type=int, default=1024)
+    ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
+                    help="f32: exact f32 MFMA (configs[1], the headline). f16: f16 operands / f32 accumulate (configs[4])")
+    ap.add_argument("--no-f16-extra", action="store_true", help="skip the extra f16 measurement appended to the f32 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
@@ -109,7 +113,7 @@ def main():
     _native.load()
 
     state_dict = synth.make_ecapa_state_dict(1234)
-    engine = EmbeddingEngine(state_dict, dev, max_batch=args.micro_batch)
+    engine = EmbeddingEngine(state_dict, dev, max_batch=args.micro_batch, precision=args.precision)
     S = args.segments
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     wav = (torch.randn((S, SAMPLES), generator=gen, device=dev, dtype=torch.float32) * 0.1).clamp_(-1.0, 1.0)
@@ -117,41 +121,66 @@ def main():
     lo, hi = sdist.row_block(n_total, rank, world)
     aff = torch.empty((hi - lo, n_total), dtype=torch.float32, device=dev)
 
-    def step():
-        emb = engine.embed(wav)
-        full = sdist.all_gather_embeddings(emb, n_total)
-        ops.cosine_affinity(full, out=aff, rows=(lo, hi))
-        return emb
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    _native.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        emb = step()
-    fence()
-    dt = time.perf_counter() - t0
-    conv_ms, conv_n, conv_flops = _native.profile_read(_native.SD_PROF_CONV_GEMM)
-    fb_ms, fb_n, fb_bytes = _native.profile_read(_native.SD_PROF_FBANK)
-    _native.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if not bool(torch.isfinite(emb).all()):
-        raise SystemExit("non-finite embeddings")
+    def measure(eng):
+        """W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
+        def step():
+            emb = eng.embed(wav)
+            full = sdist.all_gather_embeddings(emb, n_total)
+            ops.cosine_affinity(full, out=aff, rows=(lo, hi))
+            return emb
+        for _ in range(args.warmup):
+            step()
+        fence()
+        _native.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            emb = step()
+        fence()
+        dt = time.perf_counter() - t0
+        conv = _native.profile_read(_native.SD_PROF_CONV_GEMM)
+        fb = _native.profile_read(_native.SD_PROF_FBANK)
+        _native.profile_enable(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if not bool(torch.isfinite(emb).all()):
+            raise SystemExit("non-finite embeddings")
+        return dt, conv, fb, emb
+
+    dt, (conv_ms, conv_n, conv_flops), (fb_ms, fb_n, fb_bytes), emb = measure(engine)
+    extra_f16 = None
+    if args.precision == "f32" and not args.no_f16_extra:
+        emb32 = emb.clone()
+        del engine
+        torch.cuda.empty_cache()
+        eng16 = EmbeddingEngine(state_dict, dev, max_batch=args.micro_batch, precision="f16")
+        dt16, (c16_ms, c16_n, c16_flops), _, emb16 = measure(eng16)
+        cosd = 1.0 - torch.nn.functional.cosine_similarity(emb16.double(), emb32.double(), dim=1)
+        c16_tf = c16_flops / (c16_ms * 1e-3) / 1e12 if c16_ms > 0 else 0.0
+        extra_f16 = {
+            "note": "same step with f16 operands / f32 accumulation on the frame-level convs and f16 activations "
+                    "(BASELINE.json configs[4]); NOT the headline value",
+            "value": n_total * args.steps / dt16, "unit": "segments/s", "ms_per_step": dt16 / args.steps * 1e3, "dtype": "f16",
+            "max_cosine_distance_vs_f32_path": float(cosd.max().item()),
+            "roofline": {"kernel": "conv_gemm_f16_kernel", "bound": "mfma", "achieved": c16_tf, "peak": F16_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": c16_tf / F16_MFMA_PEAK_TFLOPS, "launches": c16_n,
+                         "avg_launch_ms": c16_ms / max(c16_n, 1), "share_of_step_time": c16_ms * 1e-3 / dt16},
+        }
 
     if rank == 0:
         traffic = load_traffic()
         value = n_total * args.steps / dt
         conv_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        half = args.precision == "f16"
+        mfma_peak = F16_MFMA_PEAK_TFLOPS if half else F32_MFMA_PEAK_TFLOPS
+        conv_kernel = "conv_gemm_f16_kernel" if half else "conv_gemm_f32_kernel"
         fb_gbs = fb_bytes / (fb_ms * 1e-3) / 1e9 if fb_ms > 0 else 0.0
         out = {
             "metric": "segment-embeddings/sec (2 s @16 kHz)",
@@ -164,7 +193,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.precision,
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: 10k synthetic 2 s@16 kHz segments per GPU, HIP fbank + ECAPA-TDNN forward "
@@ -175,10 +204,10 @@ def main():
                 "parallelism": f"segments sharded over {world} GPU(s), one all_gather_into_tensor per step",
             },
             "roofline": {
-                "kernel": "conv_gemm_f32_kernel", "bound": "mfma",
-                "achieved": conv_tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": conv_tflops / F32_MFMA_PEAK_TFLOPS,
-                "traffic": traffic.get("conv_gemm_f32_kernel"),
+                "kernel": conv_kernel, "bound": "mfma",
+                "achieved": conv_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": conv_tflops / mfma_peak,
+                "traffic": traffic.get(conv_kernel),
                 "launches": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
                 "flops_per_launch": conv_flops / max(conv_n, 1),
                 "share_of_step_time": conv_ms * 1e-3 / dt,
@@ -192,6 +221,8 @@ def main():
                 "share_of_step_time": fb_ms * 1e-3 / dt,
             },
         }
+        if extra_f16 is not None:
+            out["f16"] = extra_f16
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(state_dict, wav, args.cpu_seconds)
         print(json.dumps(out), flush=True)

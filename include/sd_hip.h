@@ -44,7 +44,7 @@ typedef void* sd_stream_t; /* hipStream_t */
 #define SD_ERR_WORKSPACE (-3)
 #define SD_ERR_HIP (-4)
 
-#define SD_ABI_VERSION 1
+#define SD_ABI_VERSION 2
 
 int sd_abi_version(void);
 const char* sd_last_error(void);
@@ -108,26 +108,32 @@ int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int B, int n,
  *   y[m, n] = act2( affine( act( bias[n] + sum_{j<taps} sum_{c<cin}
  *                 x[rowmap(m, j), a_col0 + c] * w[n][j][c] ) ) )
  * with m = b*T + t and rowmap reflecting t + (j - taps/2)*dil into [0, T)
- * ("same" padding, reflect mode — speechbrain Conv1d).  x: [M][lda] f32,
- * w: packed [cout][taps][cin_pad] (cin_pad = cin rounded up to 32, zero filled),
+ * ("same" padding, reflect mode — speechbrain Conv1d).  x: [M][lda],
+ * w: packed [cout][taps][cin_pad] (cin_pad = cin rounded up to the kernel's K step —
+ * 32 for f32 weights, 64 for f16 weights — zero filled),
  * y: [M][ldo] written at column o_col0.  Optional "tee": for output columns in
  * [tee_lo, tee_hi) also store y (+ tee_add[m, ta_col0 + n - tee_lo]) to
- * tee[m, n - tee_lo]; this carries the Res2Net chain's  c_{j+1} + y_j  add. */
+ * tee[m, n - tee_lo]; this carries the Res2Net chain's  c_{j+1} + y_j  add.
+ * Element types: sd_conv1d_cl_f32 is all-f32 (exact f32 MFMA).  sd_conv1d_cl_f16 takes
+ * f16 weights, x of x_dtype (f32 is converted while staging), accumulates in f32 on
+ * v_mfma_f32_32x32x16_f16 and writes y / tee (reads tee_add) as y_dtype. */
 typedef struct {
-  const float* x; int lda; int a_col0;
+  const void* x; int lda; int a_col0;
   const void* w;  int w_dtype;
-  float* y; int ldo; int o_col0;
+  void* y; int ldo; int o_col0;
   int M; int T;
   int cin; int cin_pad; int cout; int taps; int dil;
   const float* bias; int bias_per_seg; /* bias[n], or bias[(m / T) * cout + n] */
   int act;
   const float* scale; const float* shift; /* per-channel affine after act (eval BatchNorm), may be NULL */
   int act2;
-  float* tee; int ldt; int tee_lo; int tee_hi;
-  const float* tee_add; int ld_ta; int ta_col0;
+  void* tee; int ldt; int tee_lo; int tee_hi;
+  const void* tee_add; int ld_ta; int ta_col0;
+  int x_dtype; int y_dtype; /* SD_DT_*; 0 = f32 (the only choice for sd_conv1d_cl_f32) */
 } sd_conv_args;
 
 int sd_conv1d_cl_f32(const sd_conv_args* args, sd_stream_t stream);
+int sd_conv1d_cl_f16(const sd_conv_args* args, sd_stream_t stream);
 
 /* mean over the T rows of every segment: x [B*T][ld] cols [col0, col0+C) -> mean [B][C] */
 int sd_seg_mean_f32(const float* x, int ld, int col0, int B, int T, int C,
@@ -144,6 +150,14 @@ int sd_se_scale_residual_f32(const float* x, int ldx, const float* gate,
  * sd = sqrt(clamp(sum a*(h-mu)^2, eps));  out [B][2*C] = [mu | sd] */
 int sd_asp_pool_f32(const float* logit, int ldl, const float* h, int ldh,
                     int B, int T, int C, float eps, float* out, sd_stream_t stream);
+/* the same three operators with f16 (SD_DT_F16) or f32 activations; statistics, gates and
+ * attention logits stay f32 */
+int sd_seg_mean_std_dt(const void* x, int x_dtype, int ld, int col0, int B, int T, int C,
+                       int want_std, float eps, float* out, sd_stream_t stream);
+int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate, const void* res, int ldr, int r_col0,
+                            void* y, int ldy, int y_col0, int B, int T, int C, int dtype, sd_stream_t stream);
+int sd_asp_pool_dt(const float* logit, int ldl, const void* h, int h_dtype, int ldh,
+                   int B, int T, int C, float eps, float* out, sd_stream_t stream);
 
 /* ------------------------------------------------------------ ECAPA-TDNN */
 
@@ -153,6 +167,7 @@ typedef struct {
   const float* scale; /* [cout] eval-BN scale or NULL */
   const float* shift; /* [cout] eval-BN shift or NULL */
   int cin, cin_pad, cout, taps, dil;
+  int w_dtype;        /* SD_DT_F32 or SD_DT_F16 packing of w */
 } sd_layer;
 
 #define SD_MAX_RES2 15
@@ -167,7 +182,8 @@ typedef struct {
 
 /* speechbrain ECAPA_TDNN geometry (Appendix A.3 of SURVEY.md) */
 typedef struct {
-  int w_dtype;        /* SD_DT_F32 */
+  int w_dtype;        /* SD_DT_F32: everything f32.  SD_DT_F16: f16 weights + f16 activations for the
+                         frame-level layers (the per-segment M = B layers stay f32) */
   int n_mels;         /* 80 */
   int channels;       /* C = 1024: width of blocks 0..n_blocks */
   int n_blocks;       /* 3 SE-Res2Net blocks */
@@ -189,6 +205,10 @@ size_t sd_ecapa_workspace_bytes(const sd_ecapa_weights* w, int B, int T);
 
 /* feats: device f32 [B][T][n_mels] (mean-normalised fbank); emb: device f32 [B][emb_dim] */
 int sd_ecapa_forward_f32(const sd_ecapa_weights* w, const float* feats, int B, int T,
+                         float* emb, void* ws_dev, size_t ws_bytes, sd_stream_t stream);
+/* same schedule with f16 operands / f32 accumulation on the 1x1 and dilated convs and f16
+ * activations in HBM (BASELINE.json configs[4]); feats and emb stay f32 */
+int sd_ecapa_forward_f16(const sd_ecapa_weights* w, const float* feats, int B, int T,
                          float* emb, void* ws_dev, size_t ws_bytes, sd_stream_t stream);
 
 /* ------------------------------------------------------ cosine / affinity */

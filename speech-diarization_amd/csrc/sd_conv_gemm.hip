@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   }
   const int nk = p.taps * (p.cin_pad / BK);
   const int half = p.taps / 2;
-  const float* X = p.x + p.a_col0;
+  const float* X = static_cast<const float*>(p.x) + p.a_col0;
+  float* const Y = static_cast<float*>(p.y);
+  float* const TEE = static_cast<float*>(p.tee);
+  const float* const TADD = static_cast<const float*>(p.tee_add);
 
   auto set_tap = [&](int tap) {
     const int delta = (tap - half) * p.dil;
@@ -216,17 +219,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   const int n4 = n0 + cq;
   if (vec) {
     if (n4 < p.cout) {
-      const bool tee_q = p.tee && n4 >= p.tee_lo && n4 < p.tee_hi;
+      const bool tee_q = TEE && n4 >= p.tee_lo && n4 < p.tee_hi;
 #pragma unroll 4
       for (int rr = tid >> 5; rr < BM; rr += 8) {
         const int m = m0 + rr;
         if (m >= p.M) break;
         const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cq);
-        *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldo + p.o_col0 + n4) = v;
+        *reinterpret_cast<f32x4*>(Y + (size_t)m * p.ldo + p.o_col0 + n4) = v;
         if (tee_q) {
           f32x4 tv = v;
-          if (p.tee_add) tv += *reinterpret_cast<const f32x4*>(p.tee_add + (size_t)m * p.ld_ta + p.ta_col0 + (n4 - p.tee_lo));
-          *reinterpret_cast<f32x4*>(p.tee + (size_t)m * p.ldt + (n4 - p.tee_lo)) = tv;
+          if (TADD) tv += *reinterpret_cast<const f32x4*>(TADD + (size_t)m * p.ld_ta + p.ta_col0 + (n4 - p.tee_lo));
+          *reinterpret_cast<f32x4*>(TEE + (size_t)m * p.ldt + (n4 - p.tee_lo)) = tv;
         }
       }
     }
@@ -239,11 +242,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
         const int n = n4 + e;
         if (n >= p.cout) break;
         const float v = Cs[rr * LDC + cq + e];
-        p.y[(size_t)m * p.ldo + p.o_col0 + n] = v;
-        if (p.tee && n >= p.tee_lo && n < p.tee_hi) {
+        Y[(size_t)m * p.ldo + p.o_col0 + n] = v;
+        if (TEE && n >= p.tee_lo && n < p.tee_hi) {
           float tv = v;
-          if (p.tee_add) tv += p.tee_add[(size_t)m * p.ld_ta + p.ta_col0 + (n - p.tee_lo)];
-          p.tee[(size_t)m * p.ldt + (n - p.tee_lo)] = tv;
+          if (TADD) tv += TADD[(size_t)m * p.ld_ta + p.ta_col0 + (n - p.tee_lo)];
+          TEE[(size_t)m * p.ldt + (n - p.tee_lo)] = tv;
         }
       }
     }
@@ -256,6 +259,7 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
   SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_f32: null args");
   SD_CHECK_ARG(a->w_dtype == SD_DT_F32, "sd_conv1d_cl_f32: w_dtype %d not supported by the f32 operator", a->w_dtype);
   SD_CHECK_ARG(a->x && a->w && a->y, "sd_conv1d_cl_f32: null x/w/y");
+  SD_CHECK_ARG(a->x_dtype == SD_DT_F32 && a->y_dtype == SD_DT_F32, "sd_conv1d_cl_f32: x/y must be f32 (use sd_conv1d_cl_f16 for f16 activations)");
   SD_CHECK_ARG(a->M > 0 && a->T > 0 && a->M % a->T == 0, "sd_conv1d_cl_f32: M=%d must be a positive multiple of T=%d", a->M, a->T);
   SD_CHECK_ARG(a->cin > 0 && a->cin % 4 == 0, "sd_conv1d_cl_f32: cin=%d must be a positive multiple of 4", a->cin);
   SD_CHECK_ARG(a->cin_pad >= a->cin && a->cin_pad % BK == 0, "sd_conv1d_cl_f32: cin_pad=%d must be >= cin and a multiple of %d", a->cin_pad, BK);

@@ -2,9 +2,14 @@
 // EncoderClassifier.encode_batch [REF speech_encode.py:73-78] / ECAPAEncoder.forward
 // [REF ecapa_annote.py:13-22], geometry per SURVEY.md Appendix A.3.
 //
-// Activations are [B*T][C] f32, channel contiguous, resident in a caller-provided
-// workspace for the whole forward (no allocation, no synchronisation here, so the
-// call can be captured in a hipGraph).  Data movement avoided by construction:
+// Activations are [B*T][C], channel contiguous, resident in a caller-provided workspace for
+// the whole forward (no allocation, no synchronisation here, so the call can be captured in a
+// hipGraph).  Two precisions share this schedule:
+//   f32  — exact f32 MFMA everywhere (sd_ecapa_forward_f32);
+//   f16  — frame-level layers (M = B*T rows) take f16 weights / f16 activations with f32
+//          accumulation; the per-segment layers (M = B rows: SE gate, global-context bias,
+//          final FC), all statistics and the attention logits stay f32 (sd_ecapa_forward_f16).
+// Data movement avoided by construction:
 //   * block outputs are written straight into their slice of the [B*T][3C] buffer the
 //     MFA conv reads (no torch.cat copy);
 //   * tdnn1 writes into the Res2Net result buffer, so chunk 0 needs no copy;
@@ -17,88 +22,95 @@ namespace {
 
 struct Carver {
   char* base; size_t off;
-  float* take(size_t floats) {
-    float* p = reinterpret_cast<float*>(base + off);
-    off += (floats * sizeof(float) + 255) & ~(size_t)255;
+  void* take(size_t elems, size_t esz) {
+    void* p = base + off;
+    off += (elems * esz + 255) & ~(size_t)255;
     return p;
   }
 };
 
 struct Buffers {
-  float *x0, *r, *t2, *xcat, *h, *s0, *s1, *a1, *e;
+  void *x0, *r, *t2, *xcat, *h, *s0, *s1, *a1;   // activation dtype
+  float* e;                                       // attention logits, always f32
   float *semean, *seh, *gate, *stats, *gbias, *pooled;
   size_t bytes;
 };
 
 int max_i(int a, int b) { return a > b ? a : b; }
 
-Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws) {
+Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) {
   const size_t M = (size_t)B * T;
+  const size_t es = act_dtype == SD_DT_F16 ? 2 : 4;
   const int C = w->channels, Cm = w->mfa_channels, chunk = C / w->res2_scale;
   int se = 0;
   for (int i = 0; i < w->n_blocks; ++i) se = max_i(se, w->blocks[i].se1.cout);
   Carver c{static_cast<char*>(ws), 0};
   Buffers b;
-  b.x0 = c.take(M * max_i(C, w->att_channels));
-  b.r = c.take(M * C);
-  b.t2 = c.take(M * C);
-  b.xcat = c.take(M * Cm);
-  b.h = c.take(M * Cm);
-  b.s0 = c.take(M * chunk);
-  b.s1 = c.take(M * chunk);
-  b.semean = c.take((size_t)B * C);
-  b.seh = c.take((size_t)B * se);
-  b.gate = c.take((size_t)B * C);
-  b.stats = c.take((size_t)B * 2 * Cm);
-  b.gbias = c.take((size_t)B * w->att_channels);
-  b.pooled = c.take((size_t)B * 2 * Cm);
+  b.x0 = c.take(M * max_i(C, w->att_channels), es);
+  b.r = c.take(M * C, es);
+  b.t2 = c.take(M * C, es);
+  // the concatenated block outputs are dead after the MFA conv; the f32 logits reuse the space
+  b.xcat = c.take(M * Cm, 4);
+  b.h = c.take(M * Cm, es);
+  b.s0 = c.take(M * chunk, es);
+  b.s1 = c.take(M * chunk, es);
+  b.semean = static_cast<float*>(c.take((size_t)B * C, 4));
+  b.seh = static_cast<float*>(c.take((size_t)B * se, 4));
+  b.gate = static_cast<float*>(c.take((size_t)B * C, 4));
+  b.stats = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
+  b.gbias = static_cast<float*>(c.take((size_t)B * w->att_channels, 4));
+  b.pooled = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
   b.a1 = b.x0;    // block-0 output is dead once block 1 has consumed it
-  b.e = b.xcat;   // concatenated block outputs are dead after the MFA conv
+  b.e = static_cast<float*>(b.xcat);
   b.bytes = c.off;
   return b;
 }
 
-int check_layer(const char* name, const sd_layer& l, int cin, int cout, int taps) {
+int check_layer(const char* name, const sd_layer& l, int cin, int cout, int taps, int dtype) {
   SD_CHECK_ARG(l.w != nullptr, "sd_ecapa: layer %s has no weights", name);
   SD_CHECK_ARG(l.cin == cin && l.cout == cout && l.taps == taps,
                "sd_ecapa: layer %s is %d->%d k=%d, geometry wants %d->%d k=%d", name, l.cin, l.cout, l.taps, cin, cout, taps);
+  SD_CHECK_ARG(l.w_dtype == dtype, "sd_ecapa: layer %s weights are dtype %d, schedule wants %d", name, l.w_dtype, dtype);
   return SD_OK;
 }
 
-int check_weights(const sd_ecapa_weights* w) {
+int check_weights(const sd_ecapa_weights* w, int act_dtype) {
   SD_CHECK_ARG(w != nullptr, "sd_ecapa: null weights");
-  SD_CHECK_ARG(w->w_dtype == SD_DT_F32, "sd_ecapa_forward_f32: weights dtype %d is not f32", w->w_dtype);
+  SD_CHECK_ARG(w->w_dtype == act_dtype, "sd_ecapa: weights were packed for dtype %d, forward is dtype %d", w->w_dtype, act_dtype);
   SD_CHECK_ARG(w->n_blocks >= 1 && w->n_blocks <= SD_MAX_BLOCKS, "sd_ecapa: n_blocks=%d", w->n_blocks);
   SD_CHECK_ARG(w->res2_scale >= 2 && w->res2_scale - 1 <= SD_MAX_RES2, "sd_ecapa: res2_scale=%d", w->res2_scale);
-  SD_CHECK_ARG(w->channels % (4 * w->res2_scale) == 0, "sd_ecapa: channels=%d must be a multiple of 4*res2_scale", w->channels);
+  const int gran = act_dtype == SD_DT_F16 ? 8 : 4;
+  SD_CHECK_ARG(w->channels % (gran * w->res2_scale) == 0, "sd_ecapa: channels=%d must be a multiple of %d*res2_scale", w->channels, gran);
   SD_CHECK_ARG(w->mfa_channels == w->n_blocks * w->channels, "sd_ecapa: mfa_channels=%d != n_blocks*channels", w->mfa_channels);
-  SD_CHECK_ARG(w->n_mels % 4 == 0 && w->att_channels % 4 == 0, "sd_ecapa: n_mels / att_channels must be multiples of 4");
+  SD_CHECK_ARG(w->n_mels % gran == 0 && w->att_channels % gran == 0, "sd_ecapa: n_mels / att_channels must be multiples of %d", gran);
   const int C = w->channels, Cm = w->mfa_channels, chunk = C / w->res2_scale;
-  if (int e = check_layer("block0", w->block0, w->n_mels, C, w->block0.taps)) return e;
+  const int fd = act_dtype;       // frame-level layers
+  const int sd = SD_DT_F32;       // per-segment layers
+  if (int e = check_layer("block0", w->block0, w->n_mels, C, w->block0.taps, fd)) return e;
   for (int i = 0; i < w->n_blocks; ++i) {
     const sd_se_res2_block& b = w->blocks[i];
-    if (int e = check_layer("tdnn1", b.tdnn1, C, C, 1)) return e;
+    if (int e = check_layer("tdnn1", b.tdnn1, C, C, 1, fd)) return e;
     for (int j = 0; j < w->res2_scale - 1; ++j)
-      if (int e = check_layer("res2net", b.res2[j], chunk, chunk, b.res2[j].taps)) return e;
-    if (int e = check_layer("tdnn2", b.tdnn2, C, C, 1)) return e;
-    if (int e = check_layer("se1", b.se1, C, b.se1.cout, 1)) return e;
-    if (int e = check_layer("se2", b.se2, b.se1.cout, C, 1)) return e;
+      if (int e = check_layer("res2net", b.res2[j], chunk, chunk, b.res2[j].taps, fd)) return e;
+    if (int e = check_layer("tdnn2", b.tdnn2, C, C, 1, fd)) return e;
+    if (int e = check_layer("se1", b.se1, C, b.se1.cout, 1, sd)) return e;
+    if (int e = check_layer("se2", b.se2, b.se1.cout, C, 1, sd)) return e;
     SD_CHECK_ARG(b.se1.cout % 4 == 0, "sd_ecapa: se_channels must be a multiple of 4");
   }
-  if (int e = check_layer("mfa", w->mfa, Cm, Cm, 1)) return e;
-  if (int e = check_layer("asp_tdnn_h", w->asp_tdnn_h, Cm, w->att_channels, 1)) return e;
-  if (int e = check_layer("asp_tdnn_g", w->asp_tdnn_g, 2 * Cm, w->att_channels, 1)) return e;
-  if (int e = check_layer("asp_conv", w->asp_conv, w->att_channels, Cm, 1)) return e;
-  if (int e = check_layer("fc", w->fc, 2 * Cm, w->emb_dim, 1)) return e;
+  if (int e = check_layer("mfa", w->mfa, Cm, Cm, 1, fd)) return e;
+  if (int e = check_layer("asp_tdnn_h", w->asp_tdnn_h, Cm, w->att_channels, 1, fd)) return e;
+  if (int e = check_layer("asp_tdnn_g", w->asp_tdnn_g, 2 * Cm, w->att_channels, 1, sd)) return e;
+  if (int e = check_layer("asp_conv", w->asp_conv, w->att_channels, Cm, 1, fd)) return e;
+  if (int e = check_layer("fc", w->fc, 2 * Cm, w->emb_dim, 1, sd)) return e;
   return SD_OK;
 }
 
-sd_conv_args conv_of(const sd_layer& l, const float* x, int lda, int a_col0, float* y, int ldo, int o_col0,
+sd_conv_args conv_of(const sd_layer& l, const void* x, int x_dtype, int lda, int a_col0, void* y, int y_dtype, int ldo, int o_col0,
                      int M, int T, int act) {
   sd_conv_args a = {};
-  a.x = x; a.lda = lda; a.a_col0 = a_col0;
-  a.w = l.w; a.w_dtype = SD_DT_F32;
-  a.y = y; a.ldo = ldo; a.o_col0 = o_col0;
+  a.x = x; a.lda = lda; a.a_col0 = a_col0; a.x_dtype = x_dtype;
+  a.w = l.w; a.w_dtype = l.w_dtype;
+  a.y = y; a.ldo = ldo; a.o_col0 = o_col0; a.y_dtype = y_dtype;
   a.M = M; a.T = T;
   a.cin = l.cin; a.cin_pad = l.cin_pad; a.cout = l.cout; a.taps = l.taps; a.dil = l.dil;
   a.bias = l.bias; a.bias_per_seg = 0;
@@ -106,11 +118,8 @@ sd_conv_args conv_of(const sd_layer& l, const float* x, int lda, int a_col0, flo
   return a;
 }
 
-}  // namespace
-
-extern "C" size_t sd_ecapa_workspace_bytes(const sd_ecapa_weights* w, int B, int T) {
-  if (!w || B <= 0 || T <= 0 || w->res2_scale <= 0) return 0;
-  return carve(w, B, T, nullptr).bytes;
+int run_conv(const sd_conv_args& a, sd_stream_t stream) {
+  return a.w_dtype == SD_DT_F16 ? sd_conv1d_cl_f16(&a, stream) : sd_conv1d_cl_f32(&a, stream);
 }
 
 #define SD_TRY(expr)            \
@@ -119,84 +128,105 @@ extern "C" size_t sd_ecapa_workspace_bytes(const sd_ecapa_weights* w, int B, int
     if (e_ != SD_OK) return e_; \
   } while (0)
 
-extern "C" int sd_ecapa_forward_f32(const sd_ecapa_weights* w, const float* feats, int B, int T, float* emb,
-                                    void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
-  SD_TRY(check_weights(w));
-  SD_CHECK_ARG(B >= 0 && T > 0, "sd_ecapa_forward_f32: B=%d T=%d", B, T);
+int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* emb, void* ws_dev, size_t ws_bytes,
+            sd_stream_t stream, int dt) {
+  SD_TRY(check_weights(w, dt));
+  SD_CHECK_ARG(B >= 0 && T > 0, "sd_ecapa_forward: B=%d T=%d", B, T);
   if (B == 0) return SD_OK;
-  SD_CHECK_ARG(feats && emb && ws_dev, "sd_ecapa_forward_f32: null feats/emb/workspace");
-  SD_CHECK_ARG((long)B * T < (1L << 31), "sd_ecapa_forward_f32: B*T overflows int");
-  SD_CHECK_ARG(sd_aligned16(ws_dev), "sd_ecapa_forward_f32: workspace must be 16-byte aligned");
-  const Buffers b = carve(w, B, T, ws_dev);
-  if (ws_bytes < b.bytes) return sd_set_error(SD_ERR_WORKSPACE, "sd_ecapa_forward_f32: workspace %zu < %zu bytes", ws_bytes, b.bytes);
+  SD_CHECK_ARG(feats && emb && ws_dev, "sd_ecapa_forward: null feats/emb/workspace");
+  SD_CHECK_ARG((long)B * T < (1L << 31), "sd_ecapa_forward: B*T overflows int");
+  SD_CHECK_ARG(sd_aligned16(ws_dev), "sd_ecapa_forward: workspace must be 16-byte aligned");
+  const Buffers b = carve(w, B, T, ws_dev, dt);
+  if (ws_bytes < b.bytes) return sd_set_error(SD_ERR_WORKSPACE, "sd_ecapa_forward: workspace %zu < %zu bytes", ws_bytes, b.bytes);
 
   const int M = B * T;
   const int C = w->channels, Cm = w->mfa_channels, chunk = C / w->res2_scale;
+  const int F32 = SD_DT_F32;
+  const size_t es = dt == SD_DT_F16 ? 2 : 4;
+  auto col = [&](void* p, size_t c) { return static_cast<void*>(static_cast<char*>(p) + c * es); };
+  (void)col;
 
-  // block 0: TDNNBlock(n_mels -> C, k=5)
+  // block 0: TDNNBlock(n_mels -> C, k=5) on the f32 features
   {
-    sd_conv_args a = conv_of(w->block0, feats, w->n_mels, 0, b.x0, C, 0, M, T, SD_ACT_RELU);
-    SD_TRY(sd_conv1d_cl_f32(&a, stream));
+    sd_conv_args a = conv_of(w->block0, feats, F32, w->n_mels, 0, b.x0, dt, C, 0, M, T, SD_ACT_RELU);
+    SD_TRY(run_conv(a, stream));
   }
-  const float* xin = b.x0; int ldin = C, colin = 0;
+  const void* xin = b.x0; int ldin = C, colin = 0;
   for (int i = 0; i < w->n_blocks; ++i) {
     const sd_se_res2_block& blk = w->blocks[i];
     // tdnn1 -> r; chunk 1 is also teed to s0 as the first Res2Net input
     {
-      sd_conv_args a = conv_of(blk.tdnn1, xin, ldin, colin, b.r, C, 0, M, T, SD_ACT_RELU);
+      sd_conv_args a = conv_of(blk.tdnn1, xin, dt, ldin, colin, b.r, dt, C, 0, M, T, SD_ACT_RELU);
       a.tee = b.s0; a.ldt = chunk; a.tee_lo = chunk; a.tee_hi = 2 * chunk;
-      SD_TRY(sd_conv1d_cl_f32(&a, stream));
+      SD_TRY(run_conv(a, stream));
     }
     // Res2Net chain: y_j = TDNN_j(c_j + y_{j-1}), written over chunk j of r
     for (int j = 1; j < w->res2_scale; ++j) {
-      float* src = (j & 1) ? b.s0 : b.s1;
-      float* dst = (j & 1) ? b.s1 : b.s0;
-      sd_conv_args a = conv_of(blk.res2[j - 1], src, chunk, 0, b.r, C, j * chunk, M, T, SD_ACT_RELU);
+      void* src = (j & 1) ? b.s0 : b.s1;
+      void* dst = (j & 1) ? b.s1 : b.s0;
+      sd_conv_args a = conv_of(blk.res2[j - 1], src, dt, chunk, 0, b.r, dt, C, j * chunk, M, T, SD_ACT_RELU);
       if (j + 1 < w->res2_scale) {
         a.tee = dst; a.ldt = chunk; a.tee_lo = 0; a.tee_hi = chunk;
         a.tee_add = b.r; a.ld_ta = C; a.ta_col0 = (j + 1) * chunk;
       }
-      SD_TRY(sd_conv1d_cl_f32(&a, stream));
+      SD_TRY(run_conv(a, stream));
     }
     // tdnn2
     {
-      sd_conv_args a = conv_of(blk.tdnn2, b.r, C, 0, b.t2, C, 0, M, T, SD_ACT_RELU);
-      SD_TRY(sd_conv1d_cl_f32(&a, stream));
+      sd_conv_args a = conv_of(blk.tdnn2, b.r, dt, C, 0, b.t2, dt, C, 0, M, T, SD_ACT_RELU);
+      SD_TRY(run_conv(a, stream));
     }
-    // squeeze-excitation gate
-    SD_TRY(sd_seg_mean_f32(b.t2, C, 0, B, T, C, b.semean, stream));
+    // squeeze-excitation gate (per-segment, f32)
+    SD_TRY(sd_seg_mean_std_dt(b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
     {
-      sd_conv_args a = conv_of(blk.se1, b.semean, C, 0, b.seh, blk.se1.cout, 0, B, 1, SD_ACT_RELU);
-      SD_TRY(sd_conv1d_cl_f32(&a, stream));
-      sd_conv_args a2 = conv_of(blk.se2, b.seh, blk.se1.cout, 0, b.gate, C, 0, B, 1, SD_ACT_SIGMOID);
-      SD_TRY(sd_conv1d_cl_f32(&a2, stream));
+      sd_conv_args a = conv_of(blk.se1, b.semean, F32, C, 0, b.seh, F32, blk.se1.cout, 0, B, 1, SD_ACT_RELU);
+      SD_TRY(run_conv(a, stream));
+      sd_conv_args a2 = conv_of(blk.se2, b.seh, F32, blk.se1.cout, 0, b.gate, F32, C, 0, B, 1, SD_ACT_SIGMOID);
+      SD_TRY(run_conv(a2, stream));
     }
     // gate * t2 + shortcut -> slice i of the MFA input
-    SD_TRY(sd_se_scale_residual_f32(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, stream));
+    SD_TRY(sd_se_scale_residual_dt(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, dt, stream));
     xin = b.xcat; ldin = Cm; colin = i * C;
   }
   // multi-layer feature aggregation
   {
-    sd_conv_args a = conv_of(w->mfa, b.xcat, Cm, 0, b.h, Cm, 0, M, T, SD_ACT_RELU);
-    SD_TRY(sd_conv1d_cl_f32(&a, stream));
+    sd_conv_args a = conv_of(w->mfa, b.xcat, dt, Cm, 0, b.h, dt, Cm, 0, M, T, SD_ACT_RELU);
+    SD_TRY(run_conv(a, stream));
   }
   // attentive statistics pooling with global context
-  SD_TRY(sd_seg_mean_std_f32(b.h, Cm, 0, B, T, Cm, w->asp_eps, b.stats, stream));
+  SD_TRY(sd_seg_mean_std_dt(b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
   {
-    sd_conv_args g = conv_of(w->asp_tdnn_g, b.stats, 2 * Cm, 0, b.gbias, w->att_channels, 0, B, 1, SD_ACT_NONE);
+    sd_conv_args g = conv_of(w->asp_tdnn_g, b.stats, F32, 2 * Cm, 0, b.gbias, F32, w->att_channels, 0, B, 1, SD_ACT_NONE);
     g.scale = nullptr; g.shift = nullptr;
-    SD_TRY(sd_conv1d_cl_f32(&g, stream));
-    sd_conv_args a = conv_of(w->asp_tdnn_h, b.h, Cm, 0, b.a1, w->att_channels, 0, M, T, SD_ACT_RELU);
+    SD_TRY(run_conv(g, stream));
+    sd_conv_args a = conv_of(w->asp_tdnn_h, b.h, dt, Cm, 0, b.a1, dt, w->att_channels, 0, M, T, SD_ACT_RELU);
     a.bias = b.gbias; a.bias_per_seg = 1; a.act2 = SD_ACT_TANH;
-    SD_TRY(sd_conv1d_cl_f32(&a, stream));
-    sd_conv_args c = conv_of(w->asp_conv, b.a1, w->att_channels, 0, b.e, Cm, 0, M, T, SD_ACT_NONE);
-    SD_TRY(sd_conv1d_cl_f32(&c, stream));
+    SD_TRY(run_conv(a, stream));
+    sd_conv_args c = conv_of(w->asp_conv, b.a1, dt, w->att_channels, 0, b.e, F32, Cm, 0, M, T, SD_ACT_NONE);
+    SD_TRY(run_conv(c, stream));
   }
-  SD_TRY(sd_asp_pool_f32(b.e, Cm, b.h, Cm, B, T, Cm, w->asp_eps, b.pooled, stream));
+  SD_TRY(sd_asp_pool_dt(b.e, Cm, b.h, dt, Cm, B, T, Cm, w->asp_eps, b.pooled, stream));
   // asp_bn (folded into the weights by the host) + fc
   {
-    sd_conv_args a = conv_of(w->fc, b.pooled, 2 * Cm, 0, emb, w->emb_dim, 0, B, 1, SD_ACT_NONE);
-    SD_TRY(sd_conv1d_cl_f32(&a, stream));
+    sd_conv_args a = conv_of(w->fc, b.pooled, F32, 2 * Cm, 0, emb, F32, w->emb_dim, 0, B, 1, SD_ACT_NONE);
+    SD_TRY(run_conv(a, stream));
   }
   return SD_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sd_ecapa_workspace_bytes(const sd_ecapa_weights* w, int B, int T) {
+  if (!w || B <= 0 || T <= 0 || w->res2_scale <= 0) return 0;
+  return carve(w, B, T, nullptr, w->w_dtype).bytes;
+}
+
+extern "C" int sd_ecapa_forward_f32(const sd_ecapa_weights* w, const float* feats, int B, int T, float* emb,
+                                    void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
+  return forward(w, feats, B, T, emb, ws_dev, ws_bytes, stream, SD_DT_F32);
+}
+
+extern "C" int sd_ecapa_forward_f16(const sd_ecapa_weights* w, const float* feats, int B, int T, float* emb,
+                                    void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
+  return forward(w, feats, B, T, emb, ws_dev, ws_bytes, stream, SD_DT_F16);
 }

@@ -15,8 +15,24 @@ namespace {
 constexpr int CG = 64;  // channel groups (of 4) per workgroup
 constexpr int RP = 4;   // row phases per workgroup
 
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive channels as f32, from f32 or f16 storage
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const _Float16* p) {
+  const h4 h = *reinterpret_cast<const h4*>(p);
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = (float)h[e];
+  return r;
+}
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(_Float16* p, f32x4 v) {
+  h4 h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
+  *reinterpret_cast<h4*>(p) = h;
+}
 
 // part[RP][CG] reduction helper: returns the fixed-order sum over row phases (valid for rp == 0)
 __device__ __forceinline__ f32x4 combine_sum(f32x4* part, int rp, int cg, f32x4 v) {
@@ -42,26 +58,27 @@ __device__ __forceinline__ f32x4 combine_max(f32x4* part, int rp, int cg, f32x4 
   return s;
 }
 
-__global__ __launch_bounds__(256) void seg_mean_std_kernel(const float* x, int ld, int col0, int T, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void seg_mean_std_kernel(const T* x, int ld, int col0, int Tn, int C,
                                                            int want_std, float eps, float* out) {
   __shared__ f32x4 part[RP * CG];
   const int b = blockIdx.y;
   const int cg = threadIdx.x & (CG - 1), rp = threadIdx.x >> 6;
   const int c = (blockIdx.x * CG + cg) * 4;
   const bool ok = c < C;
-  const float* base = x + (size_t)b * T * ld + col0 + (ok ? c : 0);
+  const T* base = x + (size_t)b * Tn * ld + col0 + (ok ? c : 0);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (ok)
-    for (int t = rp; t < T; t += RP) s += ld4(base + (size_t)t * ld);
+    for (int t = rp; t < Tn; t += RP) s += ld4(base + (size_t)t * ld);
   s = combine_sum(part, rp, cg, s);
-  const float invT = 1.0f / (float)T;
+  const float invT = 1.0f / (float)Tn;
   const f32x4 mean = s * invT;
   const int ostride = want_std ? 2 * C : C;
   if (ok && rp == 0) st4(out + (size_t)b * ostride + c, mean);
   if (!want_std) return;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (ok)
-    for (int t = rp; t < T; t += RP) {
+    for (int t = rp; t < Tn; t += RP) {
       const f32x4 d = ld4(base + (size_t)t * ld) - mean;
       v += d * d;
     }
@@ -74,34 +91,36 @@ __global__ __launch_bounds__(256) void seg_mean_std_kernel(const float* x, int l
   }
 }
 
-__global__ __launch_bounds__(256) void se_scale_residual_kernel(const float* x, int ldx, const float* gate,
-                                                                const float* res, int ldr, int r_col0,
-                                                                float* y, int ldy, int y_col0,
-                                                                long M, int T, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_residual_kernel(const T* x, int ldx, const float* gate,
+                                                                const T* res, int ldr, int r_col0,
+                                                                T* y, int ldy, int y_col0,
+                                                                long M, int Tn, int C) {
   const int c4n = C / 4;
   const long total = M * c4n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / c4n;
     const int c = (int)(i - m * c4n) * 4;
-    const long b = m / T;
+    const long b = m / Tn;
     const f32x4 v = ld4(x + m * ldx + c) * ld4(gate + b * C + c) + ld4(res + m * ldr + r_col0 + c);
     st4(y + m * ldy + y_col0 + c, v);
   }
 }
 
-__global__ __launch_bounds__(256) void asp_pool_kernel(const float* logit, int ldl, const float* h, int ldh,
-                                                       int T, int C, float eps, float* out) {
+template <typename T>
+__global__ __launch_bounds__(256) void asp_pool_kernel(const float* logit, int ldl, const T* h, int ldh,
+                                                       int Tn, int C, float eps, float* out) {
   __shared__ f32x4 part[RP * CG];
   const int b = blockIdx.y;
   const int cg = threadIdx.x & (CG - 1), rp = threadIdx.x >> 6;
   const int c = (blockIdx.x * CG + cg) * 4;
   const bool ok = c < C;
-  const float* lb = logit + (size_t)b * T * ldl + (ok ? c : 0);
-  const float* hb = h + (size_t)b * T * ldh + (ok ? c : 0);
+  const float* lb = logit + (size_t)b * Tn * ldl + (ok ? c : 0);
+  const T* hb = h + (size_t)b * Tn * ldh + (ok ? c : 0);
   const float ninf = -INFINITY;
   f32x4 mx = {ninf, ninf, ninf, ninf};
   if (ok)
-    for (int t = rp; t < T; t += RP) {
+    for (int t = rp; t < Tn; t += RP) {
       const f32x4 l = ld4(lb + (size_t)t * ldl);
 #pragma unroll
       for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], l[e]);
@@ -109,7 +128,7 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(const float* logit, int l
   mx = combine_max(part, rp, cg, mx);
   f32x4 den = {0.f, 0.f, 0.f, 0.f}, num = {0.f, 0.f, 0.f, 0.f};
   if (ok)
-    for (int t = rp; t < T; t += RP) {
+    for (int t = rp; t < Tn; t += RP) {
       const f32x4 l = ld4(lb + (size_t)t * ldl);
       const f32x4 hv = ld4(hb + (size_t)t * ldh);
 #pragma unroll
@@ -124,7 +143,7 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(const float* logit, int l
   const f32x4 mu = num / den;
   f32x4 var = {0.f, 0.f, 0.f, 0.f};
   if (ok)
-    for (int t = rp; t < T; t += RP) {
+    for (int t = rp; t < Tn; t += RP) {
       const f32x4 l = ld4(lb + (size_t)t * ldl);
       const f32x4 hv = ld4(hb + (size_t)t * ldh);
 #pragma unroll
@@ -198,60 +217,83 @@ __global__ __launch_bounds__(256) void sim_argmax_kernel(const float* w, int ldw
   }
 }
 
-int check_cl(const char* fn, const float* x, int ld, int col0, int C) {
+int check_cl_dt(const char* fn, const void* x, int dtype, int ld, int col0, int C) {
   SD_CHECK_ARG(x != nullptr, "%s: null input", fn);
+  SD_CHECK_ARG(dtype == SD_DT_F32 || dtype == SD_DT_F16, "%s: bad dtype %d", fn, dtype);
   SD_CHECK_ARG(C > 0 && C % 4 == 0 && ld % 4 == 0 && col0 % 4 == 0 && col0 >= 0 && col0 + C <= ld,
                "%s: C=%d ld=%d col0=%d must be multiples of 4 with the slice inside the row", fn, C, ld, col0);
-  SD_CHECK_ARG(sd_aligned16(x), "%s: input must be 16-byte aligned", fn);
+  SD_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & (dtype == SD_DT_F16 ? 7u : 15u)) == 0, "%s: input is not aligned for 4-channel accesses", fn);
+  return SD_OK;
+}
+}  // namespace
+
+extern "C" int sd_seg_mean_std_dt(const void* x, int x_dtype, int ld, int col0, int B, int T, int C, int want_std, float eps,
+                                  float* out, sd_stream_t stream) {
+  if (int e = check_cl_dt("sd_seg_mean_std_dt", x, x_dtype, ld, col0, C)) return e;
+  SD_CHECK_ARG(B > 0 && T > 0 && out && sd_aligned16(out), "sd_seg_mean_std_dt: B=%d T=%d / null or unaligned output", B, T);
+  dim3 grid((C / 4 + CG - 1) / CG, B);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (x_dtype == SD_DT_F16)
+    hipLaunchKernelGGL(seg_mean_std_kernel<_Float16>, grid, dim3(256), 0, s, static_cast<const _Float16*>(x), ld, col0, T, C, want_std, eps, out);
+  else
+    hipLaunchKernelGGL(seg_mean_std_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(x), ld, col0, T, C, want_std, eps, out);
+  SD_CHECK_LAUNCH("seg_mean_std_kernel");
   return SD_OK;
 }
 
-}  // namespace
-
 extern "C" int sd_seg_mean_f32(const float* x, int ld, int col0, int B, int T, int C, float* mean, sd_stream_t stream) {
-  if (int e = check_cl("sd_seg_mean_f32", x, ld, col0, C)) return e;
-  SD_CHECK_ARG(B > 0 && T > 0 && mean && sd_aligned16(mean), "sd_seg_mean_f32: B=%d T=%d / null or unaligned output", B, T);
-  dim3 grid((C / 4 + CG - 1) / CG, B);
-  hipLaunchKernelGGL(seg_mean_std_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, col0, T, C, 0, 0.f, mean);
-  SD_CHECK_LAUNCH("seg_mean_std_kernel");
-  return SD_OK;
+  return sd_seg_mean_std_dt(x, SD_DT_F32, ld, col0, B, T, C, 0, 0.f, mean, stream);
 }
 
 extern "C" int sd_seg_mean_std_f32(const float* x, int ld, int col0, int B, int T, int C, float eps, float* stats,
                                    sd_stream_t stream) {
-  if (int e = check_cl("sd_seg_mean_std_f32", x, ld, col0, C)) return e;
-  SD_CHECK_ARG(B > 0 && T > 0 && stats && sd_aligned16(stats), "sd_seg_mean_std_f32: B=%d T=%d / null or unaligned output", B, T);
-  dim3 grid((C / 4 + CG - 1) / CG, B);
-  hipLaunchKernelGGL(seg_mean_std_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, col0, T, C, 1, eps, stats);
-  SD_CHECK_LAUNCH("seg_mean_std_kernel");
+  return sd_seg_mean_std_dt(x, SD_DT_F32, ld, col0, B, T, C, 1, eps, stats, stream);
+}
+
+extern "C" int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate, const void* res, int ldr, int r_col0,
+                                       void* y, int ldy, int y_col0, int B, int T, int C, int dtype, sd_stream_t stream) {
+  if (int e = check_cl_dt("sd_se_scale_residual(x)", x, dtype, ldx, 0, C)) return e;
+  if (int e = check_cl_dt("sd_se_scale_residual(res)", res, dtype, ldr, r_col0, C)) return e;
+  if (int e = check_cl_dt("sd_se_scale_residual(y)", y, dtype, ldy, y_col0, C)) return e;
+  SD_CHECK_ARG(gate && sd_aligned16(gate) && B > 0 && T > 0, "sd_se_scale_residual: bad gate / B / T");
+  const long M = (long)B * T;
+  const long total = M * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == SD_DT_F16)
+    hipLaunchKernelGGL(se_scale_residual_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const _Float16*>(x), ldx, gate,
+                       static_cast<const _Float16*>(res), ldr, r_col0, static_cast<_Float16*>(y), ldy, y_col0, M, T, C);
+  else
+    hipLaunchKernelGGL(se_scale_residual_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(x), ldx, gate,
+                       static_cast<const float*>(res), ldr, r_col0, static_cast<float*>(y), ldy, y_col0, M, T, C);
+  SD_CHECK_LAUNCH("se_scale_residual_kernel");
   return SD_OK;
 }
 
 extern "C" int sd_se_scale_residual_f32(const float* x, int ldx, const float* gate, const float* res, int ldr, int r_col0,
                                         float* y, int ldy, int y_col0, int B, int T, int C, sd_stream_t stream) {
-  if (int e = check_cl("sd_se_scale_residual_f32(x)", x, ldx, 0, C)) return e;
-  if (int e = check_cl("sd_se_scale_residual_f32(res)", res, ldr, r_col0, C)) return e;
-  if (int e = check_cl("sd_se_scale_residual_f32(y)", y, ldy, y_col0, C)) return e;
-  SD_CHECK_ARG(gate && sd_aligned16(gate) && B > 0 && T > 0, "sd_se_scale_residual_f32: bad gate / B / T");
-  const long M = (long)B * T;
-  const long total = M * (C / 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(se_scale_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     x, ldx, gate, res, ldr, r_col0, y, ldy, y_col0, M, T, C);
-  SD_CHECK_LAUNCH("se_scale_residual_kernel");
+  return sd_se_scale_residual_dt(x, ldx, gate, res, ldr, r_col0, y, ldy, y_col0, B, T, C, SD_DT_F32, stream);
+}
+
+extern "C" int sd_asp_pool_dt(const float* logit, int ldl, const void* h, int h_dtype, int ldh, int B, int T, int C, float eps,
+                              float* out, sd_stream_t stream) {
+  if (int e = check_cl_dt("sd_asp_pool(logit)", logit, SD_DT_F32, ldl, 0, C)) return e;
+  if (int e = check_cl_dt("sd_asp_pool(h)", h, h_dtype, ldh, 0, C)) return e;
+  SD_CHECK_ARG(B > 0 && T > 0 && out && sd_aligned16(out), "sd_asp_pool: B=%d T=%d / null or unaligned output", B, T);
+  dim3 grid((C / 4 + CG - 1) / CG, B);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h_dtype == SD_DT_F16)
+    hipLaunchKernelGGL(asp_pool_kernel<_Float16>, grid, dim3(256), 0, s, logit, ldl, static_cast<const _Float16*>(h), ldh, T, C, eps, out);
+  else
+    hipLaunchKernelGGL(asp_pool_kernel<float>, grid, dim3(256), 0, s, logit, ldl, static_cast<const float*>(h), ldh, T, C, eps, out);
+  SD_CHECK_LAUNCH("asp_pool_kernel");
   return SD_OK;
 }
 
 extern "C" int sd_asp_pool_f32(const float* logit, int ldl, const float* h, int ldh, int B, int T, int C, float eps,
                                float* out, sd_stream_t stream) {
-  if (int e = check_cl("sd_asp_pool_f32(logit)", logit, ldl, 0, C)) return e;
-  if (int e = check_cl("sd_asp_pool_f32(h)", h, ldh, 0, C)) return e;
-  SD_CHECK_ARG(B > 0 && T > 0 && out && sd_aligned16(out), "sd_asp_pool_f32: B=%d T=%d / null or unaligned output", B, T);
-  dim3 grid((C / 4 + CG - 1) / CG, B);
-  hipLaunchKernelGGL(asp_pool_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), logit, ldl, h, ldh, T, C, eps, out);
-  SD_CHECK_LAUNCH("asp_pool_kernel");
-  return SD_OK;
+  return sd_asp_pool_dt(logit, ldl, h, SD_DT_F32, ldh, B, T, C, eps, out, stream);
 }
 
 extern "C" int sd_l2norm_rows_f32(const float* x, int ldx, int N, int D, float eps_add, int sklearn_zero_guard,

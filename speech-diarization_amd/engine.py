@@ -35,12 +35,16 @@ def _pad_to(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
-def pack_conv_weight(w: np.ndarray) -> np.ndarray:
-    """[cout, cin, k] (torch Conv1d) -> [cout, k, cin_pad] f32, zero padded (kernel layout)."""
+K_ALIGN_F16 = 64  # K step of the f16 conv/GEMM kernel
+
+
+def pack_conv_weight(w: np.ndarray, dtype=np.float32) -> np.ndarray:
+    """[cout, cin, k] (torch Conv1d) -> [cout, k, cin_pad], zero padded (kernel layout);
+    f32 with cin_pad % 32 == 0, or f16 with cin_pad % 64 == 0."""
     cout, cin, k = w.shape
-    cin_pad = _pad_to(cin, K_ALIGN)
-    out = np.zeros((cout, k, cin_pad), dtype=np.float32)
-    out[:, :, :cin] = np.transpose(w, (0, 2, 1))
+    cin_pad = _pad_to(cin, K_ALIGN if dtype == np.float32 else K_ALIGN_F16)
+    out = np.zeros((cout, k, cin_pad), dtype=dtype)
+    out[:, :, :cin] = np.transpose(w, (0, 2, 1)).astype(dtype)
     return out
 
 
@@ -55,8 +59,11 @@ def bn_affine(sd: dict, prefix: str):
 class EcapaWeights:
     """ECAPA-TDNN weights packed for the HIP kernels and resident on one device."""
 
-    def __init__(self, state_dict: dict, device: torch.device):
+    def __init__(self, state_dict: dict, device: torch.device, precision: str = "f32"):
+        if precision not in ("f32", "f16"):
+            raise ValueError(f"precision must be 'f32' or 'f16', got {precision!r}")
         self.device = device
+        self.precision = precision
         self.cfg: EcapaConfig = config_from_state_dict(state_dict)
         cfg = self.cfg
         if len(set(cfg.channels[:-1])) != 1 or cfg.channels[-1] != cfg.n_blocks * cfg.channels[0]:
@@ -64,7 +71,7 @@ class EcapaWeights:
         self._keep: list[torch.Tensor] = []
         sd = state_dict
         W = N.sd_ecapa_weights()
-        W.w_dtype = N.SD_DT_F32
+        W.w_dtype = N.SD_DT_F16 if precision == "f16" else N.SD_DT_F32
         W.n_mels = cfg.input_size
         W.channels = cfg.channels[0]
         W.n_blocks = cfg.n_blocks
@@ -87,13 +94,13 @@ class EcapaWeights:
                            bn_affine(sd, f"{q}.norm.norm"), d)
             self._fill(blk.tdnn2, _np(sd[f"{p}.tdnn2.conv.conv.weight"]), _np(sd[f"{p}.tdnn2.conv.conv.bias"]),
                        bn_affine(sd, f"{p}.tdnn2.norm.norm"), 1)
-            self._fill(blk.se1, _np(sd[f"{p}.se_block.conv1.conv.weight"]), _np(sd[f"{p}.se_block.conv1.conv.bias"]), None, 1)
-            self._fill(blk.se2, _np(sd[f"{p}.se_block.conv2.conv.weight"]), _np(sd[f"{p}.se_block.conv2.conv.bias"]), None, 1)
+            self._fill(blk.se1, _np(sd[f"{p}.se_block.conv1.conv.weight"]), _np(sd[f"{p}.se_block.conv1.conv.bias"]), None, 1, per_segment=True)
+            self._fill(blk.se2, _np(sd[f"{p}.se_block.conv2.conv.weight"]), _np(sd[f"{p}.se_block.conv2.conv.bias"]), None, 1, per_segment=True)
         self._fill(W.mfa, _np(sd["mfa.conv.conv.weight"]), _np(sd["mfa.conv.conv.bias"]), bn_affine(sd, "mfa.norm.norm"), 1)
         cm = cfg.channels[-1]
         wa = _np(sd["asp.tdnn.conv.conv.weight"])  # [att, 3*cm, 1] acting on cat(h, mean, std)
         self._fill(W.asp_tdnn_h, wa[:, :cm], None, bn_affine(sd, "asp.tdnn.norm.norm"), 1)
-        self._fill(W.asp_tdnn_g, wa[:, cm:], _np(sd["asp.tdnn.conv.conv.bias"]), None, 1)
+        self._fill(W.asp_tdnn_g, wa[:, cm:], _np(sd["asp.tdnn.conv.conv.bias"]), None, 1, per_segment=True)
         self._fill(W.asp_conv, _np(sd["asp.conv.conv.weight"]), _np(sd["asp.conv.conv.bias"]), None, 1)
         # asp_bn is an affine map in front of a linear layer: fold it into fc (float64 on the host)
         s, t = bn_affine(sd, "asp_bn.norm")
@@ -101,30 +108,36 @@ class EcapaWeights:
         bf = _np(sd["fc.conv.bias"]).astype(np.float64)
         w_fold = (wf * s.astype(np.float64)[None, :]).astype(np.float32)[:, :, None]
         b_fold = (bf + wf @ t.astype(np.float64)).astype(np.float32)
-        self._fill(W.fc, w_fold, b_fold, None, 1)
+        self._fill(W.fc, w_fold, b_fold, None, 1, per_segment=True)
         self.struct = W
         self.n_params = sum(int(np.prod(v.shape)) for k, v in sd.items() if "running" not in k and "num_batches" not in k)
 
-    def _dev(self, a: np.ndarray) -> int:
-        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+    def _dev(self, a: np.ndarray, dtype=np.float32) -> int:
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.device)
         self._keep.append(t)
         return t.data_ptr()
 
-    def _fill(self, L, w: np.ndarray, bias, affine, dil: int) -> None:
+    def _fill(self, L, w: np.ndarray, bias, affine, dil: int, per_segment: bool = False) -> None:
+        """Frame-level layers (M = B*T rows) follow the engine precision; per-segment layers
+        (M = B rows: SE gate, global-context bias, FC) always stay f32."""
         cout, cin, k = w.shape
-        L.w = self._dev(pack_conv_weight(w))
+        half = self.precision == "f16" and not per_segment
+        wdt = np.float16 if half else np.float32
+        packed = pack_conv_weight(w, wdt)
+        L.w = self._dev(packed, wdt)
+        L.w_dtype = N.SD_DT_F16 if half else N.SD_DT_F32
         L.bias = self._dev(bias) if bias is not None else None
         if affine is not None:
             L.scale, L.shift = self._dev(affine[0]), self._dev(affine[1])
         else:
             L.scale, L.shift = None, None
-        L.cin, L.cin_pad, L.cout, L.taps, L.dil = cin, _pad_to(cin, K_ALIGN), cout, k, dil
+        L.cin, L.cin_pad, L.cout, L.taps, L.dil = cin, packed.shape[2], cout, k, dil
 
 
 class EmbeddingEngine:
     """fbank + ECAPA-TDNN on one GPU. Thread-safe (one forward at a time per engine)."""
 
-    def __init__(self, state_dict: dict, device="cuda", max_batch: int = 512):
+    def __init__(self, state_dict: dict, device="cuda", max_batch: int = 512, precision: str = "f32"):
         self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         if self.device.type != "cuda":
             raise RuntimeError(f"EmbeddingEngine runs on the GPU only (got device {self.device}); there is no CPU fallback")
@@ -134,9 +147,11 @@ class EmbeddingEngine:
         self.max_batch = int(max_batch)
         self._lock = threading.Lock()
         with torch.cuda.device(self.device):
-            self.weights = EcapaWeights(state_dict, self.device)
+            self.weights = EcapaWeights(state_dict, self.device, precision)
             self.plan = FbankPlan("speechbrain", n_mels=self.weights.cfg.input_size)
         self.dim = self.weights.cfg.lin_neurons
+        self.precision = precision
+        self._forward = self._lib.sd_ecapa_forward_f16 if precision == "f16" else self._lib.sd_ecapa_forward_f32
         self._ws = None
         self._ws_key = None
 
@@ -179,8 +194,8 @@ class EmbeddingEngine:
                 x = wav[lo:lo + nb]
                 N.check(self._lib.sd_fbank_f32(self.plan.handle, x.data_ptr(), nb, n, 1, feats.data_ptr(), feats.shape[1],
                                                fb_ws.data_ptr(), fb_ws.numel(), stream), "sd_fbank_f32")
-                N.check(self._lib.sd_ecapa_forward_f32(W, feats.data_ptr(), nb, T, out[lo:lo + nb].data_ptr(),
-                                                       ec_ws.data_ptr(), ec_ws.numel(), stream), "sd_ecapa_forward_f32")
+                N.check(self._forward(W, feats.data_ptr(), nb, T, out[lo:lo + nb].data_ptr(),
+                                      ec_ws.data_ptr(), ec_ws.numel(), stream), f"sd_ecapa_forward_{self.precision}")
         return out
 
     def features(self, wav: torch.Tensor) -> torch.Tensor:

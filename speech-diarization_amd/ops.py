@@ -31,27 +31,43 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def pack_weight(w: torch.Tensor | np.ndarray, device) -> torch.Tensor:
-    """[cout, cin, k] -> packed [cout, k, cin_pad] on `device`."""
+def pack_weight(w: torch.Tensor | np.ndarray, device, dtype=torch.float32) -> torch.Tensor:
+    """[cout, cin, k] -> packed [cout, k, cin_pad] on `device` (f32: cin_pad % 32 == 0, f16: % 64)."""
     from .engine import pack_conv_weight
     w = w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
-    return torch.from_numpy(pack_conv_weight(w.astype(np.float32))).to(device)
+    npdt = np.float16 if dtype == torch.float16 else np.float32
+    return torch.from_numpy(pack_conv_weight(w.astype(np.float32), npdt)).to(device)
+
+
+def _dt(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return N.SD_DT_F32
+    if t == torch.float16:
+        return N.SD_DT_F16
+    raise TypeError(f"unsupported dtype {t}")
 
 
 def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, T: int, *, cin: int, dil: int = 1, bias=None, bias_per_seg=False,
               act=None, scale=None, shift=None, act2=None, a_col0: int = 0, out: torch.Tensor | None = None,
               o_col0: int = 0, tee: torch.Tensor | None = None, tee_lo: int = 0, tee_hi: int = 0,
-              tee_add: torch.Tensor | None = None, ta_col0: int = 0) -> torch.Tensor:
-    """Channel-last conv1d ("same", reflect) with the fused TDNN epilogue. x: [M, lda], returns [M, ldo]."""
+              tee_add: torch.Tensor | None = None, ta_col0: int = 0, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+    """Channel-last conv1d ("same", reflect) with the fused TDNN epilogue. x: [M, lda], returns [M, ldo].
+    f32 weights -> exact-f32 operator; f16 weights -> f16-operand / f32-accumulate operator (x f32 or
+    f16, output `out_dtype`)."""
     _need_cuda(x, w_packed, bias, scale, shift, out, tee, tee_add)
     lib = N.load()
     cout, taps, cin_pad = w_packed.shape
     M = x.shape[0]
+    half = w_packed.dtype == torch.float16
     if out is None:
-        out = torch.empty((M, cout), dtype=torch.float32, device=x.device)
+        out = torch.empty((M, cout), dtype=out_dtype or (torch.float16 if half else torch.float32), device=x.device)
     a = N.sd_conv_args()
     a.x, a.lda, a.a_col0 = x.data_ptr(), x.stride(0), a_col0
-    a.w, a.w_dtype = w_packed.data_ptr(), N.SD_DT_F32
+    a.w, a.w_dtype = w_packed.data_ptr(), _dt(w_packed.dtype)
+    a.x_dtype, a.y_dtype = _dt(x.dtype), _dt(out.dtype)
+    for extra in (tee, tee_add):
+        if extra is not None and extra.dtype != out.dtype:
+            raise TypeError("tee / tee_add must have the output dtype")
     a.y, a.ldo, a.o_col0 = out.data_ptr(), out.stride(0), o_col0
     a.M, a.T = M, T
     a.cin, a.cin_pad, a.cout, a.taps, a.dil = cin, cin_pad, cout, taps, dil
@@ -63,7 +79,8 @@ def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, T: int, *, cin: int, dil:
         if tee_add is not None:
             a.tee_add, a.ld_ta, a.ta_col0 = tee_add.data_ptr(), tee_add.stride(0), ta_col0
     with torch.cuda.device(x.device):
-        N.check(lib.sd_conv1d_cl_f32(C.byref(a), _stream(x)), "sd_conv1d_cl_f32")
+        fn, name = (lib.sd_conv1d_cl_f16, "sd_conv1d_cl_f16") if half else (lib.sd_conv1d_cl_f32, "sd_conv1d_cl_f32")
+        N.check(fn(C.byref(a), _stream(x)), name)
     return out
 
 

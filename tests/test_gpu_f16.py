@@ -1,0 +1,149 @@
+"""The f16-operand / f32-accumulate path (BASELINE.json configs[4]) against the float64 oracle.
+
+Operands are rounded to f16 (11-bit significand, the precision of the TF32 matmuls the reference
+enables on its CUDA path), sums are f32.  The bar is north_star's: embeddings within 1e-3 cosine of
+the reference CPU path and identical cluster assignments; the per-operator bound is the f16
+rounding of inputs and outputs (2^-11 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos_dist(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+def _ref_conv_cl(x, w, b, T, dil):
+    M, cin = x.shape
+    xt = x.view(M // T, T, cin).transpose(1, 2)
+    pad = dil * (w.shape[2] - 1) // 2
+    if pad:
+        xt = F.pad(xt, (pad, pad), mode="reflect")
+    return F.conv1d(xt, w, b, dilation=dil).transpose(1, 2).reshape(M, -1)
+
+
+@pytest.mark.parametrize("B,T,cin,cout,k,dil,xdt,ydt", [
+    (3, 201, 1024, 1024, 1, 1, torch.float16, torch.float16),
+    (5, 101, 128, 128, 3, 3, torch.float16, torch.float16),
+    (2, 201, 80, 256, 5, 1, torch.float32, torch.float16),     # stem: f32 features in, f16 out, cin % 64 != 0
+    (4, 33, 128, 3072, 1, 1, torch.float16, torch.float32),    # attention logits stay f32
+    (3, 50, 256, 200, 1, 1, torch.float16, torch.float16),     # cout not a multiple of the tile
+])
+def test_conv1d_cl_f16_matches_f64(dev, B, T, cin, cout, k, dil, xdt, ydt):
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(B * 77 + T)
+    x = torch.randn(B * T, cin, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    xq = x.to(xdt)
+    wq = w.half()
+    # reference on the SAME rounded operands, float64 arithmetic: isolates accumulation + output rounding
+    ref = torch.relu(_ref_conv_cl(xq.double(), wq.double(), b.double(), T, dil)) * scale.double() + shift.double()
+    got = ops.conv1d_cl(xq.to(dev), ops.pack_weight(w, dev, torch.float16), T, cin=cin, dil=dil, bias=b.to(dev), act="relu",
+                        scale=scale.to(dev), shift=shift.to(dev), out_dtype=ydt)
+    torch.cuda.synchronize()
+    assert got.dtype == ydt
+    tol = (1e-3 if ydt == torch.float16 else 2e-5) * max(1.0, ref.abs().max().item())
+    assert (got.cpu().double() - ref).abs().max().item() < tol
+
+
+def test_conv1d_cl_f16_tee(dev):
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, T, C, hid = 3, 57, 256, 64
+    xbig = torch.randn(B * T, C, generator=g).half()
+    w = (torch.randn(hid, hid, 3, generator=g) / 14).half()
+    x_d = xbig.to(dev)
+    out = torch.zeros(B * T, C, device=dev, dtype=torch.float16)
+    tee = torch.zeros(B * T, hid, device=dev, dtype=torch.float16)
+    ops.conv1d_cl(x_d, ops.pack_weight(w.float(), dev, torch.float16), T, cin=hid, dil=2, act="relu", a_col0=64, out=out, o_col0=64,
+                  tee=tee, tee_lo=0, tee_hi=hid, tee_add=x_d, ta_col0=128)
+    torch.cuda.synchronize()
+    y = torch.relu(_ref_conv_cl(xbig[:, 64:128].double().contiguous(), w.double(), None, T, 2))
+    assert (out[:, 64:128].cpu().double() - y).abs().max() < 2e-3
+    assert out[:, :64].abs().max() == 0 and out[:, 128:].abs().max() == 0
+    assert (tee.cpu().double() - (y + xbig[:, 128:192].double())).abs().max() < 4e-3
+
+
+def test_pool_kernels_on_f16_activations(dev):
+    import ctypes as C
+    from speech_diarization_amd import _native as N
+    lib = N.load()
+    g = torch.Generator().manual_seed(4)
+    B, T, Cc = 3, 201, 512
+    x = (torch.randn(B * T, Cc, generator=g) * 2 + 0.5).half()
+    xd = x.to(dev)
+    st = torch.empty(B, 2 * Cc, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N.check(lib.sd_seg_mean_std_dt(xd.data_ptr(), N.SD_DT_F16, Cc, 0, B, T, Cc, 1, C.c_float(1e-12), st.data_ptr(), stream), "mean_std")
+    xr = x.double().view(B, T, Cc)
+    assert (st[:, :Cc].cpu().double() - xr.mean(1)).abs().max() < 1e-5
+    assert (st[:, Cc:].cpu().double() - xr.std(1, unbiased=False)).abs().max() < 1e-5
+    logit = torch.randn(B * T, Cc, generator=g) * 3
+    out = torch.empty(B, 2 * Cc, device=dev)
+    logit_d = logit.to(dev)
+    N.check(lib.sd_asp_pool_dt(logit_d.data_ptr(), Cc, xd.data_ptr(), N.SD_DT_F16, Cc, B, T, Cc, C.c_float(1e-12), out.data_ptr(), stream), "asp")
+    a = torch.softmax(logit.double().view(B, T, Cc), dim=1)
+    mu = (a * xr).sum(1)
+    assert (out[:, :Cc].cpu().double() - mu).abs().max() < 1e-5
+    gate = torch.rand(B, Cc, generator=g)
+    res = torch.randn(B * T, Cc, generator=g).half()
+    y = torch.empty(B * T, Cc, device=dev, dtype=torch.float16)
+    gate_d, res_d = gate.to(dev), res.to(dev)      # keep the device copies alive across the async launch
+    N.check(lib.sd_se_scale_residual_dt(xd.data_ptr(), Cc, gate_d.data_ptr(), res_d.data_ptr(), Cc, 0, y.data_ptr(), Cc, 0,
+                                        B, T, Cc, N.SD_DT_F16, stream), "se")
+    ref = x.double() * gate.double().repeat_interleave(T, 0) + res.double()
+    assert (y.cpu().double() - ref).abs().max() < 1e-2       # one f16 rounding of a value up to ~10
+
+
+@pytest.mark.parametrize("width,B,n", [(128, 5, 16000), (128, 3, 32000)])
+def test_ecapa_f16_small_geometry(dev, width, B, n):
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(21, synth.EcapaConfig.small(width))
+    wav = synth.synthetic_segments(3, B, n)
+    got = EmbeddingEngine(sd, dev, precision="f16").embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
+    cd = _cos_dist(got, ref)
+    assert cd.max() < 1e-4, cd                # north_star bar: 1e-3
+
+
+def test_ecapa_f16_full_geometry(dev):
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    wav = synth.synthetic_segments(0, 4, 32000)
+    got = EmbeddingEngine(sd, dev, precision="f16").embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
+    cd = _cos_dist(got, ref)
+    assert cd.max() < 1e-3, cd
+    print("f16 full-geometry max cosine distance", cd.max())
+
+
+def test_f16_and_f32_engines_give_the_same_clusters(dev):
+    """identical cluster assignments from the f16 path, the f32 path and the CPU path"""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import cluster, ops, synth
+    from speech_diarization_amd.diarization_baseline import gather_windows, speech_windows
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234, synth.EcapaConfig.small(128))
+    conv = synth.synthetic_conversation(40.0, 3, seed=2)
+    speech = [(s, e) for s, e, _ in conv.turns]
+    starts, _, _ = speech_windows(speech, len(conv.wav), 16000, 2.0, 0.25)
+    wav = gather_windows(conv.wav, starts, 32000)
+    labels = []
+    for emb in (EmbeddingEngine(sd, dev, precision="f16").embed(torch.from_numpy(wav).to(dev)).cpu().numpy(),
+                EmbeddingEngine(sd, dev, precision="f32").embed(torch.from_numpy(wav).to(dev)).cpu().numpy(),
+                pipeline_ref.encode_batch_ref(sd, wav, torch.float32)):
+        K = ops.cosine_affinity(torch.from_numpy(cluster.center(emb).astype(np.float32)).to(dev)).cpu().numpy()
+        labels.append(cluster.relabel_by_first_appearance(cluster.spectral(K, 3)))
+    assert np.array_equal(labels[0], labels[1]) and np.array_equal(labels[1], labels[2])
+    assert len(set(labels[0].tolist())) == 3

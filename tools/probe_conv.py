@@ -22,17 +22,20 @@ def main():
     ap.add_argument("--dil", type=int, default=1)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--zeros", action="store_true")
+    ap.add_argument("--f16", action="store_true")
     a = ap.parse_args()
     from speech_diarization_amd import ops
     dev = torch.device("cuda", 0)
     M = a.B * a.T
     x = torch.zeros(M, a.cin, device=dev) if a.zeros else torch.randn(M, a.cin, device=dev)
     w = torch.randn(a.cout, a.cin, a.taps) / (a.cin * a.taps) ** 0.5
-    wp = ops.pack_weight(w, dev)
+    if a.f16:
+        x = x.half()
+    wp = ops.pack_weight(w, dev, torch.float16 if a.f16 else torch.float32)
     bias = torch.randn(a.cout, device=dev)
     scale = torch.rand(a.cout, device=dev) + 0.5
     shift = torch.randn(a.cout, device=dev)
-    out = torch.empty(M, a.cout, device=dev)
+    out = torch.empty(M, a.cout, device=dev, dtype=torch.float16 if a.f16 else torch.float32)
     ops.conv1d_cl(x, wp, a.T, cin=a.cin, dil=a.dil, bias=bias, act="relu", scale=scale, shift=shift, out=out)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.reps + 1)]
