@@ -46,8 +46,9 @@ def needs_build() -> bool:
     return STAMP.read_text().strip() != _fingerprint()
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, stamp: bool = False) -> Path:
+    """stamp=True: diagnostic build with in-kernel timeline stamps (-DSD_STAMP); never ship or time it."""
+    if not force and not stamp and not needs_build():
         return LIB_PATH
     obj_dir = CSRC / "obj"
     obj_dir.mkdir(exist_ok=True)
@@ -55,6 +56,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         _hipcc(), f"--offload-arch={OFFLOAD_ARCH}", "-O3", "-std=c++17", "-fPIC",
         "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-function",
     ]
+    if stamp:
+        common.append("-DSD_STAMP")
     procs = []
     objs = []
     for src in SOURCES:
@@ -77,10 +80,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if res.returncode != 0:
         sys.stderr.write(res.stdout)
         raise RuntimeError("link of libsd_hip.so failed")
-    STAMP.write_text(_fingerprint())
+    STAMP.write_text("stamp-build" if stamp else _fingerprint())
     return LIB_PATH
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, stamp="--stamp" in sys.argv)
     print(path)

@@ -18,6 +18,7 @@
 // element r to MFMA r, so MFMA r sums k in {k0 + r, k0 + 4 + r}; A and B use the
 // same permutation, and the sum over k is order independent up to rounding.
 #include "sd_common.h"
+#include "sd_epilogue.h"
 
 namespace {
 
@@ -27,15 +28,6 @@ constexpr int BK = 32;
 constexpr int LDP = BK + 4;  // padded LDS row, floats
 constexpr int LDC = BN + 4;  // padded row of the epilogue's C tile in LDS
 static_assert(BM * LDC <= 2 * (BM + BN) * LDP, "C tile must fit in the operand stage");
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  switch (act) {
-    case SD_ACT_RELU: return fmaxf(v, 0.0f);
-    case SD_ACT_TANH: return tanhf(v);
-    case SD_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    default: return v;
-  }
-}
 
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p, const int vec) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -78,9 +70,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   const int nk = p.taps * (p.cin_pad / BK);
   const int half = p.taps / 2;
   const float* X = static_cast<const float*>(p.x) + p.a_col0;
-  float* const Y = static_cast<float*>(p.y);
-  float* const TEE = static_cast<float*>(p.tee);
-  const float* const TADD = static_cast<const float*>(p.tee_add);
 
   auto set_tap = [&](int tap) {
     const int delta = (tap - half) * p.dil;
@@ -179,78 +168,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
     cur ^= 1;
   }
 
-  // ---- epilogue, phase 1: bias / activation / BN affine on the accumulators (lane owns
-  // column n, 16 rows per MFMA tile), result staged in LDS as a [BM][LDC] tile.  The main
-  // loop's last barrier has retired every read of As/Bs, so the stage can be reused.
+  // ---- epilogue: raw accumulators -> LDS C tile (the main loop's last barrier has retired every
+  // read of the operand stage), then sd_store_tile applies bias / activation / BN affine and
+  // issues 16-byte row-contiguous stores (sd_epilogue.h)
   float* Cs = smem;
   const int hrow = (lane >> 5) * 4;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int cl = wn * 64 + ni * 32 + (lane & 31);
-    const int n = n0 + cl;
-    const bool nok = n < p.cout;
-    const float bias_n = (nok && p.bias && !p.bias_per_seg) ? p.bias[n] : 0.f;
-    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
-    const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-        float v = acc[mi][ni][r];
-        if (p.bias_per_seg) {
-          const int m = m0 + rl;
-          v += (nok && m < p.M) ? p.bias[(size_t)(m / p.T) * p.cout + n] : 0.f;
-        } else {
-          v += bias_n;
-        }
-        v = apply_act(v, p.act);
-        v = v * sc + sh;
-        v = apply_act(v, p.act2);
-        Cs[rl * LDC + cl] = v;
+        Cs[rl * LDC + cl] = acc[mi][ni][r];
       }
     }
   }
   __syncthreads();
-
-  // ---- phase 2: row-contiguous stores, 16 bytes per lane (a half-wave writes one 512-byte
-  // tile row), plus the optional tee  y (+ tee_add)  for the Res2Net chain.
-  const int cq = (tid & 31) * 4;   // tile column of this thread's float4
-  const int n4 = n0 + cq;
-  if (vec) {
-    if (n4 < p.cout) {
-      const bool tee_q = TEE && n4 >= p.tee_lo && n4 < p.tee_hi;
-#pragma unroll 4
-      for (int rr = tid >> 5; rr < BM; rr += 8) {
-        const int m = m0 + rr;
-        if (m >= p.M) break;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cq);
-        *reinterpret_cast<f32x4*>(Y + (size_t)m * p.ldo + p.o_col0 + n4) = v;
-        if (tee_q) {
-          f32x4 tv = v;
-          if (TADD) tv += *reinterpret_cast<const f32x4*>(TADD + (size_t)m * p.ld_ta + p.ta_col0 + (n4 - p.tee_lo));
-          *reinterpret_cast<f32x4*>(TEE + (size_t)m * p.ldt + (n4 - p.tee_lo)) = tv;
-        }
-      }
-    }
-  } else {
-    for (int rr = tid >> 5; rr < BM; rr += 8) {
-      const int m = m0 + rr;
-      if (m >= p.M) break;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = n4 + e;
-        if (n >= p.cout) break;
-        const float v = Cs[rr * LDC + cq + e];
-        Y[(size_t)m * p.ldo + p.o_col0 + n] = v;
-        if (TEE && n >= p.tee_lo && n < p.tee_hi) {
-          float tv = v;
-          if (TADD) tv += TADD[(size_t)m * p.ld_ta + p.ta_col0 + (n - p.tee_lo)];
-          TEE[(size_t)m * p.ldt + (n - p.tee_lo)] = tv;
-        }
-      }
-    }
-  }
+  sd_store_tile<float, BM, BN, 256>(p, Cs, LDC, m0, n0, tid, vec);
 }
 
 }  // namespace
@@ -278,9 +214,9 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
       SD_CHECK_ARG(a->ta_col0 >= 0 && a->ta_col0 + (a->tee_hi - a->tee_lo) <= a->ld_ta, "sd_conv1d_cl_f32: tee_add slice outside row");
   }
   // 16-byte epilogue stores need every touched row slice 16-byte aligned
-  int vec = a->cout % 4 == 0 && a->ldo % 4 == 0 && a->o_col0 % 4 == 0 && sd_aligned16(a->y);
+  int vec = a->cout % 8 == 0 && a->ldo % 4 == 0 && a->o_col0 % 4 == 0 && sd_aligned16(a->y);
   if (a->tee) {
-    vec = vec && a->tee_lo % 4 == 0 && a->tee_hi % 4 == 0 && a->ldt % 4 == 0 && sd_aligned16(a->tee);
+    vec = vec && a->tee_lo % 8 == 0 && a->tee_hi % 8 == 0 && a->ldt % 4 == 0 && sd_aligned16(a->tee);
     if (a->tee_add) vec = vec && a->ld_ta % 4 == 0 && a->ta_col0 % 4 == 0 && sd_aligned16(a->tee_add);
   }
   const long tiles_m = (a->M + BM - 1) / BM;
