@@ -500,9 +500,15 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
     if (a->tee_add) vec = vec && a->ld_ta % 8 == 0 && a->ta_col0 % 8 == 0 && sd_aligned16(a->tee_add);
   }
   const bool xa = a->x_dtype == SD_DT_F16, ya = a->y_dtype == SD_DT_F16;
-  // f16 activations take the LDS-DMA ring kernel; SD_F16_NO_GLDS=1 keeps the register-staged one (A/B runs)
-  static const bool no_glds = [] { const char* e = getenv("SD_F16_NO_GLDS"); return e && e[0] == '1'; }();
-  if (xa && !no_glds) return ya ? launch_glds<_Float16>(a, vec, stream) : launch_glds<float>(a, vec, stream);
+  // Kernel choice, measured per shape on MI355X (tools/probe_conv.py, B*T = 205 824 rows): the 256x128
+  // LDS-DMA ring wins only on the big square MFA conv (3072x3072: 800 vs 785 TFLOP/s); the
+  // register-staged 128x128 kernel with two workgroups per CU is faster everywhere else
+  // (1024x1024: 588 vs 541, Res2Net 128x384: 327 vs 275, 128->3072: 205 vs 185).
+  // SD_F16_GLDS=0 / 1 forces one or the other for A/B runs.
+  static const int force_glds = [] { const char* e = getenv("SD_F16_GLDS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  const bool big = a->cout >= 2048 && (long)a->taps * a->cin >= 2048;
+  const bool use_glds = force_glds < 0 ? big : force_glds == 1;
+  if (xa && use_glds) return ya ? launch_glds<_Float16>(a, vec, stream) : launch_glds<float>(a, vec, stream);
   if (xa && ya) return launch<_Float16, _Float16>(a, vec, stream);
   if (xa && !ya) return launch<_Float16, float>(a, vec, stream);
   if (!xa && ya) return launch<float, _Float16>(a, vec, stream);

@@ -246,6 +246,11 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const FbankArgs p)
   }
 }
 
+__global__ void fill_i32_kernel(int* p, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 // top_db floor (relative to the utterance max) and per-bin mean removal over T.
 // One workgroup per utterance; thread (r, c) walks rows r, r+R, ... of column c.
 __global__ void fbank_finalize_kernel(float* out, int ld_out, int T, int n_mels, const int* maxbuf,
@@ -392,7 +397,10 @@ extern "C" int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int
   const long tiles = a.flat ? ((long)B * T + FT - 1) / FT : (long)B * ((T + FT - 1) / FT);
   const long blocks = (tiles + WAVES - 1) / WAVES;
   SD_CHECK_ARG(blocks < (1L << 31), "sd_fbank_f32: grid too large");
-  SD_CHECK_HIP(hipMemsetAsync(a.maxbuf, 0x80, (size_t)B * sizeof(int), stream));
+  // reset the per-utterance max keys with a kernel, not hipMemsetAsync: a byte-pattern memset node
+  // replayed from a captured hipGraph did not reproduce the eager result (configs[3] test)
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a.maxbuf, B, (int)0x80808080);
+  SD_CHECK_LAUNCH("fill_i32_kernel");
   const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

@@ -1,0 +1,89 @@
+"""BASELINE.json configs[3]: streaming feed, fixed-shape hop captured in a hipGraph.
+
+A real-time feed of `channels` microphones delivers `hop_s` of audio per hop; every hop the last
+`window_s` of each channel is embedded.  The shape is fixed ([channels, window samples]), so the
+whole hop — HIP fbank, the ~45 launches of the ECAPA-TDNN forward — is captured once into a
+hipGraph and replayed (launch-bound inner loop: one graph launch instead of ~45 kernel launches).
+Nothing in the reference streams; the embedding call being replaced is the same
+`ecapa_encode_batch` [REF speech_encode.py:73-78].
+
+`OnlineClusterer` is a host-side leader-follower agglomeration over the hop embeddings (cosine
+threshold, running unit-norm centroids) — the "online AHC" of configs[3].
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .engine import EmbeddingEngine
+
+
+class StreamingEmbedder:
+    def __init__(self, engine: EmbeddingEngine, channels: int = 16, window_s: float = 2.0, hop_s: float = 0.25, sr: int = 16000,
+                 use_graph: bool = True):
+        self.engine = engine
+        self.channels, self.sr = channels, sr
+        self.win = int(round(window_s * sr))
+        self.hop = int(round(hop_s * sr))
+        dev = engine.device
+        self.ring = torch.zeros((channels, self.win), dtype=torch.float32, device=dev)      # last window_s per channel
+        self._static_in = torch.zeros((channels, self.win), dtype=torch.float32, device=dev)
+        self._static_out = None
+        self._graph = None
+        self.use_graph = use_graph
+        if use_graph:
+            self._capture()
+
+    def _capture(self) -> None:
+        dev = self.engine.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                     # warm-up outside capture: allocates the engine workspace
+                self.engine.embed(self._static_in)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_out = self.engine.embed(self._static_in)
+
+    def push(self, chunk: torch.Tensor) -> torch.Tensor:
+        """chunk: f32 [channels, hop samples] (device or host) -> embeddings [channels, 192] of the updated windows."""
+        if chunk.shape != (self.channels, self.hop):
+            raise ValueError(f"expected a [{self.channels}, {self.hop}] hop, got {tuple(chunk.shape)}")
+        chunk = chunk.to(self.ring.device, dtype=torch.float32, non_blocking=True)
+        self.ring = torch.cat((self.ring[:, self.hop:], chunk), dim=1)
+        if self._graph is None:
+            return self.engine.embed(self.ring)
+        self._static_in.copy_(self.ring)
+        self._graph.replay()
+        return self._static_out
+
+
+class OnlineClusterer:
+    """Leader-follower online agglomeration: an embedding joins the closest centroid if its cosine is at
+    least `threshold`, else it founds a new speaker; centroids are running sums re-normalised on use."""
+
+    def __init__(self, threshold: float = 0.7, max_speakers: int = 16):
+        self.threshold, self.max_speakers = threshold, max_speakers
+        self.sums: list[np.ndarray] = []
+        self.counts: list[int] = []
+
+    def assign(self, embs: np.ndarray) -> np.ndarray:
+        out = np.empty(len(embs), dtype=int)
+        for i, e in enumerate(np.asarray(embs, dtype=np.float64)):
+            e = e / (np.linalg.norm(e) + 1e-8)
+            if self.sums:
+                C = np.stack(self.sums)
+                C = C / (np.linalg.norm(C, axis=1, keepdims=True) + 1e-8)
+                sims = C @ e
+                k = int(np.argmax(sims))
+                if sims[k] >= self.threshold or len(self.sums) >= self.max_speakers:
+                    self.sums[k] += e
+                    self.counts[k] += 1
+                    out[i] = k
+                    continue
+            self.sums.append(e.copy())
+            self.counts.append(1)
+            out[i] = len(self.sums) - 1
+        return out

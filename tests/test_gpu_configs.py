@@ -1,0 +1,120 @@
+"""BASELINE.json configs[2], [3], [4] as parity-test cases (GPU).
+
+configs[2]: long multi-speaker meeting, VAD segments -> windows sharded round-robin -> gathered -> clustered;
+configs[3]: streaming 16-channel feed, hipGraph-captured fbank+ECAPA per hop, online agglomeration;
+configs[4]: batch job — f16 ECAPA (covered by tests/test_gpu_f16.py) and the 50k x 50k tiled cosine affinity,
+            checked at full size through size-independent properties.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_sd(width=128):
+    from speech_diarization_amd import synth
+    return synth.make_ecapa_state_dict(1234, synth.EcapaConfig.small(width))
+
+
+def test_config2_sharded_meeting_matches_unsharded_and_cpu(dev):
+    """10 min, 8 voices: windows are embedded (a) in one piece, (b) as 8 round-robin shards that are
+    gathered and de-interleaved (the W = 8 layout, executed rank by rank on this one GPU).  Rows are
+    independent in every kernel, so (b) must be BITWISE equal to (a); cluster labels must equal the CPU path's."""
+    from oracle.ecapa_ref import EcapaRef
+    from oracle.pipeline_ref import encode_batch_ref
+    from speech_diarization_amd import cluster, dist as sdist, ops, synth, vad
+    from speech_diarization_amd.diarization_baseline import gather_windows, speech_windows
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = _small_sd()
+    conv = synth.synthetic_conversation(600.0, 8, seed=0)
+    scorer = vad.SileroVAD(model=vad.EnergyScorer())
+    mask = vad.morph_open_close(vad.hysteresis_binarize(scorer.probs(conv.wav), 0.6, 0.4), 10.0)
+    speech = vad.mask_to_segments(mask, 10.0, 350.0, 100.0, 40.0)
+    starts, _, _ = speech_windows(speech, len(conv.wav), 16000, 2.0, 0.25)
+    wav = torch.from_numpy(gather_windows(conv.wav, starts, 32000)).to(dev)
+    n = wav.shape[0]
+    assert n > 1000
+    eng = EmbeddingEngine(sd, dev, max_batch=256)
+    whole = eng.embed(wav)
+    W = 8
+    rows = sdist.shard_rows(n, W)
+    gathered = torch.zeros((W, rows, 192), device=dev)
+    for r in range(W):
+        idx = torch.from_numpy(sdist.shard_indices(n, r, W)).to(dev)
+        gathered[r, : idx.numel()] = eng.embed(wav[idx])
+    merged = sdist.deinterleave(gathered, n, W)
+    assert torch.equal(merged, whole)
+    # clustering on the gathered embeddings vs the CPU path (subsampled: every 4th window keeps the CPU leg short)
+    sub = np.arange(0, n, 4)
+    e_gpu = whole[sub].cpu().numpy()
+    net = EcapaRef(sd, torch.float32)
+    e_cpu = encode_batch_ref(sd, wav[sub].cpu().numpy(), torch.float32, net)
+    labs = []
+    for e in (e_gpu, e_cpu):
+        K = ops.cosine_affinity(torch.from_numpy(cluster.center(e).astype(np.float32)).to(dev)).cpu().numpy()
+        labs.append(cluster.relabel_by_first_appearance(cluster.spectral(K, 8)))
+    assert np.array_equal(labs[0], labs[1])
+    assert len(set(labs[0].tolist())) == 8
+
+
+def test_config3_streaming_graph_replay_matches_eager(dev):
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    from speech_diarization_amd.streaming import OnlineClusterer, StreamingEmbedder
+    eng = EmbeddingEngine(_small_sd(), dev, max_batch=16)
+    st = StreamingEmbedder(eng, channels=16, window_s=2.0, hop_s=0.25)
+    eager = StreamingEmbedder(EmbeddingEngine(_small_sd(), dev, max_batch=16), channels=16, use_graph=False)
+    feed = synth.synthetic_segments(5, 16, 4000 * 12)
+    lat = []
+    for h in range(12):
+        chunk = torch.from_numpy(feed[:, h * 4000:(h + 1) * 4000]).to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a = st.push(chunk).clone()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+        b = eager.push(chunk)
+        assert a.shape == (16, 192)
+        assert torch.equal(a, b)                        # same kernels, same order: bitwise equal
+    print(f"streaming hop latency (small geometry): p50 {np.median(lat) * 1e3:.3f} ms")
+    with pytest.raises(ValueError):
+        st.push(torch.zeros(16, 100))
+    oc = OnlineClusterer(threshold=0.5)
+    x = np.eye(192)[:3]
+    labels = oc.assign(np.concatenate([x, x + 0.01, x[:1]]))
+    assert labels.tolist() == [0, 1, 2, 0, 1, 2, 0]
+
+
+def test_config4_affinity_50k_properties(dev):
+    """50 000 x 50 000 f32 affinity (10 GB) in one call: unit diagonal, symmetry, bounded, planted
+    duplicates / zero rows, and agreement of a row block with the row-block entry point."""
+    from speech_diarization_amd import ops
+    n, d = 50000, 192
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn((n, d), generator=g, device=dev)
+    x[123] = 0.0
+    x[40000] = 3.0 * x[17]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = ops.cosine_affinity(x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"50k x 50k affinity: {dt * 1e3:.1f} ms, {4.0 * n * n / dt / 1e12:.2f} TB/s written, {384.0 * n * n / dt / 1e12:.1f} TFLOP/s")
+    diag = torch.diagonal(K)
+    keep = torch.ones(n, dtype=torch.bool, device=dev); keep[123] = False
+    assert (diag[keep] - 1.0).abs().max() < 1e-5 and diag[123] == 0
+    assert bool(torch.all(K[123] == 0)) and bool(torch.all(K[:, 123] == 0))
+    assert abs(K[40000, 17].item() - 1.0) < 1e-5
+    assert K.abs().max() <= 1.0 + 1e-5
+    for lo in (0, 20000, 49000):                           # symmetry, checked block-wise to bound memory
+        blk = K[lo:lo + 1000, :]
+        assert torch.equal(blk[:, lo:lo + 1000], blk[:, lo:lo + 1000].T) or (blk[:, lo:lo + 1000] - blk[:, lo:lo + 1000].T).abs().max() < 2e-7
+        assert (blk - K[:, lo:lo + 1000].T).abs().max() < 2e-7
+    rows = ops.cosine_affinity(x, rows=(31000, 31500))
+    assert torch.equal(rows, K[31000:31500])
+    sub = x[:2000].cpu().numpy()
+    from sklearn.metrics.pairwise import cosine_similarity
+    assert np.abs(K[:2000, :2000].cpu().numpy() - cosine_similarity(sub)).max() < 2e-6

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs[3] and configs[4] (not the headline bench):
+
+  * streaming: 16 channels x 250 ms hop, 2 s window, hipGraph-captured fbank + ECAPA-TDNN (full
+    spkrec-ecapa geometry), per-hop latency p50 / p99 and hops/s, graph replay vs eager launches;
+  * 50k x 50k cosine affinity in one call.
+
+    python tools/bench_configs.py [--hops 200]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def stream_latency(state_dict, dev, precision, use_graph, hops):
+    from speech_diarization_amd.engine import EmbeddingEngine
+    from speech_diarization_amd.streaming import StreamingEmbedder
+    eng = EmbeddingEngine(state_dict, dev, max_batch=16, precision=precision)
+    st = StreamingEmbedder(eng, channels=16, window_s=2.0, hop_s=0.25, use_graph=use_graph)
+    chunk = (torch.randn(16, 4000, device=dev) * 0.1)
+    for _ in range(10):
+        st.push(chunk)
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(hops):
+        t0 = time.perf_counter()
+        st.push(chunk)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.asarray(lat)
+    return {"precision": precision, "graph": use_graph, "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+            "hops_per_s": float(1e3 / lat.mean()), "realtime_factor_16ch": float(250.0 / np.percentile(lat, 99))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hops", type=int, default=200)
+    a = ap.parse_args()
+    from speech_diarization_amd import ops, synth
+    dev = torch.device("cuda", 0)
+    sd = synth.make_ecapa_state_dict(1234)
+    out = {"streaming": [stream_latency(sd, dev, p, g, a.hops) for p in ("f32", "f16") for g in (True, False)]}
+    x = torch.randn(50000, 192, device=dev)
+    K = torch.empty(50000, 50000, device=dev)
+    ops.cosine_affinity(x, out=K)
+    torch.cuda.synchronize()
+    t = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ops.cosine_affinity(x, out=K)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter() - t0)
+    dt = min(t)
+    out["affinity_50k"] = {"ms": dt * 1e3, "tflops": 384.0 * 50000 ** 2 / dt / 1e12, "write_tb_s": 4.0 * 50000 ** 2 / dt / 1e12}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
