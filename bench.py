@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--segments", type=int, default=10000, help="segments per rank per step")
-    ap.add_argument("--micro-batch", type=int, default=1024)
+    ap.add_argument("--micro-batch", type=int, default=5000)
     ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
                     help="f32: exact f32 MFMA (configs[1], the headline). f16: f16 operands / f32 accumulate (configs[4])")
     ap.add_argument("--no-f16-extra", action="store_true", help="skip the extra f16 measurement appended to the f32 line")

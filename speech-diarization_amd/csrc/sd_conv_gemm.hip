@@ -189,6 +189,66 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   sd_store_tile<float, BM, BN, 256>(p, Cs, LDC, m0, n0, tid, vec);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Per-segment layers (SE squeeze/excite, global-context bias, final FC): M = B rows only, so the
+// 128x128 kernel above would run on 8-16 workgroups.  Here a workgroup owns a 32x32 output tile
+// and its 4 waves split K four ways (exact-f32 32x32x2 MFMA, operands straight from global/L2 in
+// 16-byte pieces, same k-permutation as above); the four partial tiles are summed through LDS in
+// wave order, so the result does not depend on timing.
+constexpr int SK_T = 32;
+constexpr int SK_LD = SK_T + 1;
+
+__global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const sd_conv_args p) {
+  __shared__ float red[4 * SK_T * SK_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n_tiles = (p.cout + SK_T - 1) / SK_T;
+  const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+  const int m0 = tile_m * SK_T, n0 = tile_n * SK_T;
+  const int r = lane & 31, h = lane >> 5;
+  int m = m0 + r; m = m < p.M ? m : p.M - 1;
+  int n = n0 + r; n = n < p.cout ? n : p.cout - 1;
+  // this wave's K range: a quarter of cin_pad, a multiple of 8 (cin_pad % 32 == 0)
+  const int kq = p.cin_pad / 4;
+  const int kb = wid * kq;
+  const float* xa = static_cast<const float*>(p.x) + (size_t)m * p.lda + p.a_col0 + 4 * h;
+  const float* wb = static_cast<const float*>(p.w) + (size_t)n * p.cin_pad + 4 * h;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k = kb; k < kb + kq; k += 8) {
+    // columns past cin exist only in the zero-padded weights; do not read x there
+    const f32x4 a = (k + 4 * h < p.cin) ? *reinterpret_cast<const f32x4*>(xa + k) : z4;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(wb + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+  }
+  float* mine = red + wid * SK_T * SK_LD;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mine[((i & 3) + 8 * (i >> 2) + 4 * h) * SK_LD + r] = acc[i];
+  __syncthreads();
+  // 1024 outputs / 256 threads: thread -> row tid / 8, columns 4 * (tid % 8) .. +3
+  const int row = tid >> 3, c0 = (tid & 7) * 4;
+  const int mo = m0 + row;
+  if (mo >= p.M) return;
+  float* Y = static_cast<float*>(p.y);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int no = n0 + c0 + e;
+    if (no >= p.cout) break;
+    float v = red[row * SK_LD + c0 + e];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += red[w * SK_T * SK_LD + row * SK_LD + c0 + e];
+    if (p.bias) v += p.bias_per_seg ? p.bias[(size_t)(mo / p.T) * p.cout + no] : p.bias[no];
+    v = sd_apply_act(v, p.act);
+    v = v * (p.scale ? p.scale[no] : 1.f) + (p.shift ? p.shift[no] : 0.f);
+    v = sd_apply_act(v, p.act2);
+    Y[(size_t)mo * p.ldo + p.o_col0 + no] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
@@ -222,6 +282,14 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
   const long tiles_m = (a->M + BM - 1) / BM;
   const long tiles_n = (a->cout + BN - 1) / BN;
   SD_CHECK_ARG(tiles_m * tiles_n < (1L << 31), "sd_conv1d_cl_f32: grid too large");
+  // too few 128x128 tiles to fill the chip (per-segment layers): 32x32 tiles with in-workgroup split-K
+  if (a->T == 1 && a->taps == 1 && !a->tee && tiles_m * tiles_n < 128) {
+    const long g = (long)((a->M + SK_T - 1) / SK_T) * ((a->cout + SK_T - 1) / SK_T);
+    SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream), 2.0 * (double)a->M * (double)a->cout * (double)a->cin);
+    hipLaunchKernelGGL(skinny_gemm_f32_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+    SD_CHECK_LAUNCH("skinny_gemm_f32_kernel");
+    return SD_OK;
+  }
   const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
