@@ -109,10 +109,12 @@ def test_std_clamp_on_constant_input(dev):
     assert torch.allclose(ms[:, C:], torch.full((B, C), 1e-6, device=dev), rtol=1e-6, atol=0)
 
 
-def test_asp_pool(dev):
+@pytest.mark.parametrize("B,T,C", [(4, 201, 768),      # LDS-resident kernel (one HBM pass)
+                                   (2, 400, 256),      # T too long for the LDS budget -> streaming kernel
+                                   (3, 50, 100)])      # C not a multiple of 32 -> streaming kernel
+def test_asp_pool(dev, B, T, C):
     from speech_diarization_amd import ops
     g = torch.Generator().manual_seed(3)
-    B, T, C = 4, 201, 768
     logit = torch.randn(B * T, C, generator=g, dtype=torch.float64) * 4
     h = torch.randn(B * T, C, generator=g, dtype=torch.float64)
     out = ops.asp_pool(logit.float().to(dev), h.float().to(dev), B, T)
