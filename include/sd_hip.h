@@ -150,13 +150,13 @@ int sd_se_scale_residual_f32(const float* x, int ldx, const float* gate,
  * sd = sqrt(clamp(sum a*(h-mu)^2, eps));  out [B][2*C] = [mu | sd] */
 int sd_asp_pool_f32(const float* logit, int ldl, const float* h, int ldh,
                     int B, int T, int C, float eps, float* out, sd_stream_t stream);
-/* the same three operators with f16 (SD_DT_F16) or f32 activations; statistics, gates and
- * attention logits stay f32 */
+/* the same three operators with f16 (SD_DT_F16) or f32 activations (logits and h share the dtype);
+ * statistics and gates stay f32 */
 int sd_seg_mean_std_dt(const void* x, int x_dtype, int ld, int col0, int B, int T, int C,
                        int want_std, float eps, float* out, sd_stream_t stream);
 int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate, const void* res, int ldr, int r_col0,
                             void* y, int ldy, int y_col0, int B, int T, int C, int dtype, sd_stream_t stream);
-int sd_asp_pool_dt(const float* logit, int ldl, const void* h, int h_dtype, int ldh,
+int sd_asp_pool_dt(const void* logit, int ldl, const void* h, int dtype, int ldh,
                    int B, int T, int C, float eps, float* out, sd_stream_t stream);
 
 /* ------------------------------------------------------------ ECAPA-TDNN */

@@ -8,7 +8,7 @@
 //   f32  — exact f32 MFMA everywhere (sd_ecapa_forward_f32);
 //   f16  — frame-level layers (M = B*T rows) take f16 weights / f16 activations with f32
 //          accumulation; the per-segment layers (M = B rows: SE gate, global-context bias,
-//          final FC), all statistics and the attention logits stay f32 (sd_ecapa_forward_f16).
+//          final FC) and all statistics stay f32 (sd_ecapa_forward_f16).
 // Data movement avoided by construction:
 //   * block outputs are written straight into their slice of the [B*T][3C] buffer the
 //     MFA conv reads (no torch.cat copy);
@@ -30,8 +30,7 @@ struct Carver {
 };
 
 struct Buffers {
-  void *x0, *r, *t2, *xcat, *h, *s0, *s1, *a1;   // activation dtype
-  float* e;                                       // attention logits, always f32
+  void *x0, *r, *t2, *xcat, *h, *s0, *s1, *a1, *e;   // activation dtype (e = attention logits)
   float *semean, *seh, *gate, *stats, *gbias, *pooled;
   size_t bytes;
 };
@@ -49,8 +48,8 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.x0 = c.take(M * max_i(C, w->att_channels), es);
   b.r = c.take(M * C, es);
   b.t2 = c.take(M * C, es);
-  // the concatenated block outputs are dead after the MFA conv; the f32 logits reuse the space
-  b.xcat = c.take(M * Cm, 4);
+  // the concatenated block outputs are dead after the MFA conv; the attention logits reuse the space
+  b.xcat = c.take(M * Cm, es);
   b.h = c.take(M * Cm, es);
   b.s0 = c.take(M * chunk, es);
   b.s1 = c.take(M * chunk, es);
@@ -61,7 +60,7 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.gbias = static_cast<float*>(c.take((size_t)B * w->att_channels, 4));
   b.pooled = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
   b.a1 = b.x0;    // block-0 output is dead once block 1 has consumed it
-  b.e = static_cast<float*>(b.xcat);
+  b.e = b.xcat;
   b.bytes = c.off;
   return b;
 }
@@ -202,7 +201,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     sd_conv_args a = conv_of(w->asp_tdnn_h, b.h, dt, Cm, 0, b.a1, dt, w->att_channels, 0, M, T, SD_ACT_RELU);
     a.bias = b.gbias; a.bias_per_seg = 1; a.act2 = SD_ACT_TANH;
     SD_TRY(run_conv(a, stream));
-    sd_conv_args c = conv_of(w->asp_conv, b.a1, dt, w->att_channels, 0, b.e, F32, Cm, 0, M, T, SD_ACT_NONE);
+    sd_conv_args c = conv_of(w->asp_conv, b.a1, dt, w->att_channels, 0, b.e, dt, Cm, 0, M, T, SD_ACT_NONE);
     SD_TRY(run_conv(c, stream));
   }
   SD_TRY(sd_asp_pool_dt(b.e, Cm, b.h, dt, Cm, B, T, Cm, w->asp_eps, b.pooled, stream));

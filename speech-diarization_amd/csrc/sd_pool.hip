@@ -108,14 +108,14 @@ __global__ __launch_bounds__(256) void se_scale_residual_kernel(const T* x, int 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void asp_pool_kernel(const float* logit, int ldl, const T* h, int ldh,
+__global__ __launch_bounds__(256) void asp_pool_kernel(const T* logit, int ldl, const T* h, int ldh,
                                                        int Tn, int C, float eps, float* out) {
   __shared__ f32x4 part[RP * CG];
   const int b = blockIdx.y;
   const int cg = threadIdx.x & (CG - 1), rp = threadIdx.x >> 6;
   const int c = (blockIdx.x * CG + cg) * 4;
   const bool ok = c < C;
-  const float* lb = logit + (size_t)b * Tn * ldl + (ok ? c : 0);
+  const T* lb = logit + (size_t)b * Tn * ldl + (ok ? c : 0);
   const T* hb = h + (size_t)b * Tn * ldh + (ok ? c : 0);
   const float ninf = -INFINITY;
   f32x4 mx = {ninf, ninf, ninf, ninf};
@@ -173,7 +173,7 @@ constexpr int APC = 32;   // channels per workgroup
 constexpr int APR = 8;    // row phases
 
 template <typename T>
-__global__ __launch_bounds__(256) void asp_pool_lds_kernel(const float* logit, int ldl, const T* h, int ldh,
+__global__ __launch_bounds__(256) void asp_pool_lds_kernel(const T* logit, int ldl, const T* h, int ldh,
                                                            int Tn, int C, float eps, float* out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sl = sm;                    // [Tn][APC] logits
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void asp_pool_lds_kernel(const float* logit, i
   // stage: 8 lanes x 4 channels per row, 32 rows per pass (C % 32 == 0 is checked on the host)
   {
     const int q = (tid & 7) * 4, r = tid >> 3;
-    const float* lb = logit + (size_t)b * Tn * ldl + c0 + q;
+    const T* lb = logit + (size_t)b * Tn * ldl + c0 + q;
     const T* hb = h + (size_t)b * Tn * ldh + c0 + q;
     for (int t = r; t < Tn; t += 32) {
       st4(sl + t * APC + q, ld4(lb + (size_t)t * ldl));
@@ -341,27 +341,26 @@ extern "C" int sd_se_scale_residual_f32(const float* x, int ldx, const float* ga
   return sd_se_scale_residual_dt(x, ldx, gate, res, ldr, r_col0, y, ldy, y_col0, B, T, C, SD_DT_F32, stream);
 }
 
-extern "C" int sd_asp_pool_dt(const float* logit, int ldl, const void* h, int h_dtype, int ldh, int B, int T, int C, float eps,
+extern "C" int sd_asp_pool_dt(const void* logit, int ldl, const void* h, int dtype, int ldh, int B, int T, int C, float eps,
                               float* out, sd_stream_t stream) {
-  if (int e = check_cl_dt("sd_asp_pool(logit)", logit, SD_DT_F32, ldl, 0, C)) return e;
-  if (int e = check_cl_dt("sd_asp_pool(h)", h, h_dtype, ldh, 0, C)) return e;
+  if (int e = check_cl_dt("sd_asp_pool(logit)", logit, dtype, ldl, 0, C)) return e;
+  if (int e = check_cl_dt("sd_asp_pool(h)", h, dtype, ldh, 0, C)) return e;
   SD_CHECK_ARG(B > 0 && T > 0 && out && sd_aligned16(out), "sd_asp_pool: B=%d T=%d / null or unaligned output", B, T);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = ((size_t)2 * T * APC + 2 * APR * APC) * sizeof(float);
+  const bool half = dtype == SD_DT_F16;
+  const _Float16* lh = static_cast<const _Float16*>(logit); const _Float16* hh = static_cast<const _Float16*>(h);
+  const float* lf = static_cast<const float*>(logit); const float* hf = static_cast<const float*>(h);
   if (C % APC == 0 && lds <= 64 * 1024) {
     dim3 g2(C / APC, B);
-    if (h_dtype == SD_DT_F16)
-      hipLaunchKernelGGL(asp_pool_lds_kernel<_Float16>, g2, dim3(256), lds, s, logit, ldl, static_cast<const _Float16*>(h), ldh, T, C, eps, out);
-    else
-      hipLaunchKernelGGL(asp_pool_lds_kernel<float>, g2, dim3(256), lds, s, logit, ldl, static_cast<const float*>(h), ldh, T, C, eps, out);
+    if (half) hipLaunchKernelGGL(asp_pool_lds_kernel<_Float16>, g2, dim3(256), lds, s, lh, ldl, hh, ldh, T, C, eps, out);
+    else hipLaunchKernelGGL(asp_pool_lds_kernel<float>, g2, dim3(256), lds, s, lf, ldl, hf, ldh, T, C, eps, out);
     SD_CHECK_LAUNCH("asp_pool_lds_kernel");
     return SD_OK;
   }
   dim3 grid((C / 4 + CG - 1) / CG, B);
-  if (h_dtype == SD_DT_F16)
-    hipLaunchKernelGGL(asp_pool_kernel<_Float16>, grid, dim3(256), 0, s, logit, ldl, static_cast<const _Float16*>(h), ldh, T, C, eps, out);
-  else
-    hipLaunchKernelGGL(asp_pool_kernel<float>, grid, dim3(256), 0, s, logit, ldl, static_cast<const float*>(h), ldh, T, C, eps, out);
+  if (half) hipLaunchKernelGGL(asp_pool_kernel<_Float16>, grid, dim3(256), 0, s, lh, ldl, hh, ldh, T, C, eps, out);
+  else hipLaunchKernelGGL(asp_pool_kernel<float>, grid, dim3(256), 0, s, lf, ldl, hf, ldh, T, C, eps, out);
   SD_CHECK_LAUNCH("asp_pool_kernel");
   return SD_OK;
 }

@@ -85,7 +85,7 @@ def test_pool_kernels_on_f16_activations(dev):
     xr = x.double().view(B, T, Cc)
     assert (st[:, :Cc].cpu().double() - xr.mean(1)).abs().max() < 1e-5
     assert (st[:, Cc:].cpu().double() - xr.std(1, unbiased=False)).abs().max() < 1e-5
-    logit = torch.randn(B * T, Cc, generator=g) * 3
+    logit = (torch.randn(B * T, Cc, generator=g) * 3).half()
     out = torch.empty(B, 2 * Cc, device=dev)
     logit_d = logit.to(dev)
     N.check(lib.sd_asp_pool_dt(logit_d.data_ptr(), Cc, xd.data_ptr(), N.SD_DT_F16, Cc, B, T, Cc, C.c_float(1e-12), out.data_ptr(), stream), "asp")
