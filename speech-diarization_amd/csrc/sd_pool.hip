@@ -164,36 +164,45 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(const T* logit, int ldl, 
 }
 
 
-// Attentive statistics pooling with the (b, 32-channel) tile of logits and h resident in LDS:
-// one pass over HBM instead of three (the streaming kernel above measured 12.6 GB of traffic per
-// 1024-segment launch against 5 GB algorithmic).  256 threads = 32 channels x 8 row phases; the
-// three reductions (max, sum/weighted sum, weighted variance) are combined through LDS in a fixed
-// order.  Used when T * 32 * 8 bytes fit the LDS budget; longer segments take the streaming kernel.
-constexpr int APC = 32;   // channels per workgroup
-constexpr int APR = 8;    // row phases
+// Attentive statistics pooling with the (segment, channel-tile) block of logits and h resident in
+// LDS: one pass over HBM instead of three (the streaming kernel above measured 12.6 GB of traffic
+// per 1024-segment launch against 5 GB algorithmic).  The tile is 128 bytes of channels wide (32
+// f32 or 64 f16 channels: whole cache lines per row) and kept in the storage type; 256 threads =
+// APC channels x (256 / APC) row phases; the three reductions (max, sum / weighted sum, weighted
+// variance) are combined through LDS in a fixed order.  Longer segments (T * 256 bytes above the
+// LDS budget) take the streaming kernel.
+template <typename T> struct AspTile { static constexpr int APC = 32; };
+template <> struct AspTile<_Float16> { static constexpr int APC = 64; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(_Float16 v) { return (float)v; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void asp_pool_lds_kernel(const T* logit, int ldl, const T* h, int ldh,
                                                            int Tn, int C, float eps, float* out) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* sl = sm;                    // [Tn][APC] logits
-  float* sh = sm + (size_t)Tn * APC; // [Tn][APC] h
-  float* red = sh + (size_t)Tn * APC; // [APR][APC] x 2
+  constexpr int APC = AspTile<T>::APC;
+  constexpr int APR = 256 / APC;
+  constexpr int VEC = 16 / sizeof(T);          // elements per 16-byte piece
+  constexpr int TPR = APC / VEC;               // threads per row while staging (8)
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  T* sl = reinterpret_cast<T*>(sm_raw);                        // [Tn][APC] logits
+  T* sh = sl + (size_t)Tn * APC;                               // [Tn][APC] h
+  float* red = reinterpret_cast<float*>(sm_raw + (((size_t)2 * Tn * APC * sizeof(T) + 15) & ~(size_t)15));  // [2][APR][APC]
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * APC;
   const int tid = threadIdx.x;
-  // stage: 8 lanes x 4 channels per row, 32 rows per pass (C % 32 == 0 is checked on the host)
   {
-    const int q = (tid & 7) * 4, r = tid >> 3;
+    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    const int q = (tid % TPR) * VEC, r = tid / TPR;
     const T* lb = logit + (size_t)b * Tn * ldl + c0 + q;
     const T* hb = h + (size_t)b * Tn * ldh + c0 + q;
-    for (int t = r; t < Tn; t += 32) {
-      st4(sl + t * APC + q, ld4(lb + (size_t)t * ldl));
-      st4(sh + t * APC + q, ld4(hb + (size_t)t * ldh));
+    for (int t = r; t < Tn; t += 256 / TPR) {
+      *reinterpret_cast<vec_t*>(sl + t * APC + q) = *reinterpret_cast<const vec_t*>(lb + (size_t)t * ldl);
+      *reinterpret_cast<vec_t*>(sh + t * APC + q) = *reinterpret_cast<const vec_t*>(hb + (size_t)t * ldh);
     }
   }
   __syncthreads();
-  const int c = tid & (APC - 1), rp = tid >> 5;
+  const int c = tid % APC, rp = tid / APC;
   auto combine = [&](float v, float* buf, bool is_max) {
     buf[rp * APC + c] = v;
     __syncthreads();
@@ -204,22 +213,22 @@ __global__ __launch_bounds__(256) void asp_pool_lds_kernel(const T* logit, int l
     return s;
   };
   float mx = -INFINITY;
-  for (int t = rp; t < Tn; t += APR) mx = fmaxf(mx, sl[t * APC + c]);
+  for (int t = rp; t < Tn; t += APR) mx = fmaxf(mx, to_f32(sl[t * APC + c]));
   mx = combine(mx, red, true);
   float den = 0.f, num = 0.f;
   for (int t = rp; t < Tn; t += APR) {
-    const float w = expf(sl[t * APC + c] - mx);
-    sl[t * APC + c] = w;                       // keep the weight: the variance pass reuses it
+    const float w = expf(to_f32(sl[t * APC + c]) - mx);
     den += w;
-    num += w * sh[t * APC + c];
+    num += w * to_f32(sh[t * APC + c]);
   }
   den = combine(den, red, false);
   num = combine(num, red + APR * APC, false);
   const float mu = num / den;
   float var = 0.f;
   for (int t = rp; t < Tn; t += APR) {
-    const float d = sh[t * APC + c] - mu;
-    var += sl[t * APC + c] * d * d;
+    const float w = expf(to_f32(sl[t * APC + c]) - mx);
+    const float d = to_f32(sh[t * APC + c]) - mu;
+    var += w * d * d;
   }
   var = combine(var, red, false);
   if (rp == 0) {
@@ -347,12 +356,13 @@ extern "C" int sd_asp_pool_dt(const void* logit, int ldl, const void* h, int dty
   if (int e = check_cl_dt("sd_asp_pool(h)", h, dtype, ldh, 0, C)) return e;
   SD_CHECK_ARG(B > 0 && T > 0 && out && sd_aligned16(out), "sd_asp_pool: B=%d T=%d / null or unaligned output", B, T);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t lds = ((size_t)2 * T * APC + 2 * APR * APC) * sizeof(float);
   const bool half = dtype == SD_DT_F16;
+  const int apc = half ? AspTile<_Float16>::APC : AspTile<float>::APC;
+  const size_t lds = (((size_t)2 * T * 128 + 15) & ~(size_t)15) + (size_t)2 * 256 * sizeof(float);   // 128-byte tile rows
   const _Float16* lh = static_cast<const _Float16*>(logit); const _Float16* hh = static_cast<const _Float16*>(h);
   const float* lf = static_cast<const float*>(logit); const float* hf = static_cast<const float*>(h);
-  if (C % APC == 0 && lds <= 64 * 1024) {
-    dim3 g2(C / APC, B);
+  if (C % apc == 0 && lds <= 64 * 1024) {
+    dim3 g2(C / apc, B);
     if (half) hipLaunchKernelGGL(asp_pool_lds_kernel<_Float16>, g2, dim3(256), lds, s, lh, ldl, hh, ldh, T, C, eps, out);
     else hipLaunchKernelGGL(asp_pool_lds_kernel<float>, g2, dim3(256), lds, s, lf, ldl, hf, ldh, T, C, eps, out);
     SD_CHECK_LAUNCH("asp_pool_lds_kernel");
