@@ -91,19 +91,35 @@ __global__ __launch_bounds__(256) void seg_mean_std_kernel(const T* x, int ld, i
   }
 }
 
+// y = x * gate[segment] + res, 16 bytes per lane, no 64-bit index arithmetic: a workgroup walks whole
+// rows (grid-stride over row groups), a thread keeps its channel group for all of them, the
+// segment index costs one 32-bit division per row.
 template <typename T>
 __global__ __launch_bounds__(256) void se_scale_residual_kernel(const T* x, int ldx, const float* gate,
                                                                 const T* res, int ldr, int r_col0,
                                                                 T* y, int ldy, int y_col0,
-                                                                long M, int Tn, int C) {
-  const int c4n = C / 4;
-  const long total = M * c4n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / c4n;
-    const int c = (int)(i - m * c4n) * 4;
-    const long b = m / Tn;
-    const f32x4 v = ld4(x + m * ldx + c) * ld4(gate + b * C + c) + ld4(res + m * ldr + r_col0 + c);
-    st4(y + m * ldy + y_col0 + c, v);
+                                                                int M, int Tn, int C) {
+  constexpr int VEC = 16 / sizeof(T);                 // 4 f32 or 8 f16 channels per lane
+  typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+  const int groups = C / VEC;                          // channel groups per row
+  const int gpr = groups < 256 ? groups : 256;         // threads used per row
+  const int rows_per_pass = 256 / gpr;
+  const int tr = threadIdx.x / gpr, tg = threadIdx.x % gpr;
+  if (tr >= rows_per_pass) return;
+  for (int m = blockIdx.x * rows_per_pass + tr; m < M; m += gridDim.x * rows_per_pass) {
+    const float* g = gate + (size_t)(m / Tn) * C;
+    const T* xr = x + (size_t)m * ldx;
+    const T* rr = res + (size_t)m * ldr + r_col0;
+    T* yr = y + (size_t)m * ldy + y_col0;
+    for (int gq = tg; gq < groups; gq += gpr) {
+      const int c = gq * VEC;
+      const vec_t xv = *reinterpret_cast<const vec_t*>(xr + c);
+      const vec_t rv = *reinterpret_cast<const vec_t*>(rr + c);
+      vec_t o;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = (T)((float)xv[e] * g[c + e] + (float)rv[e]);
+      *reinterpret_cast<vec_t*>(yr + c) = o;
+    }
   }
 }
 
@@ -330,10 +346,15 @@ extern "C" int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate
   if (int e = check_cl_dt("sd_se_scale_residual(res)", res, dtype, ldr, r_col0, C)) return e;
   if (int e = check_cl_dt("sd_se_scale_residual(y)", y, dtype, ldy, y_col0, C)) return e;
   SD_CHECK_ARG(gate && sd_aligned16(gate) && B > 0 && T > 0, "sd_se_scale_residual: bad gate / B / T");
-  const long M = (long)B * T;
-  const long total = M * (C / 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const int M = B * T;
+  const int vec = dtype == SD_DT_F16 ? 8 : 4;
+  SD_CHECK_ARG(C % vec == 0 && ldx % vec == 0 && ldr % vec == 0 && ldy % vec == 0 && r_col0 % vec == 0 && y_col0 % vec == 0,
+               "sd_se_scale_residual: C / strides / column offsets must be multiples of %d", vec);
+  SD_CHECK_ARG(sd_aligned16(x) && sd_aligned16(res) && sd_aligned16(y), "sd_se_scale_residual: x / res / y must be 16-byte aligned");
+  const int groups = C / vec;
+  const int rpp = 256 / (groups < 256 ? groups : 256);
+  long blocks = ((long)M + rpp - 1) / rpp;
+  if (blocks > 256 * 32) blocks = 256 * 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == SD_DT_F16)
     hipLaunchKernelGGL(se_scale_residual_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const _Float16*>(x), ldx, gate,
