@@ -43,7 +43,7 @@ def install_stubs():
              "torchaudio.transforms", "speechbrain", "speechbrain.inference", "speechbrain.inference.classifiers",
              "dacite", "pyannote", "pyannote.audio", "pyannote.core", "pyannote.audio.core", "pyannote.audio.core.model",
              "pyannote.audio.pipelines", "pyannote.audio.pipelines.utils", "pyannote.audio.pipelines.utils.hook",
-             "jsonargparse"]
+             "jsonargparse", "soundfile"]
     for n in names:
         sys.modules[n] = _Inert(n)
     sys.modules["numba"].jit = lambda *a, **k: (lambda f: f)
@@ -207,6 +207,28 @@ def main():
                         n_windows=len(starts), valid=valid, window_labels=wl, labels_to_segments=[(s.start, s.end, s.spk) for s in l2s],
                         merge_adjacent=[(s.start, s.end, s.spk) for s in adj]))
     out["anti_stick_diarize"] = asd
+
+    # ---- diar_diag score helpers (pure numpy in the reference)
+    import tempfile
+    import diar_diag as rdd
+    dd = []
+    for seed in (21, 22):
+        e = synth.normal(seed, "golden.dd.e", (40, 24)).astype(np.float64)
+        e[:20] += 2.0 * synth.normal(seed, "golden.dd.c0", (1, 24))
+        e[20:] += 2.0 * synth.normal(seed, "golden.dd.c1", (1, 24))
+        cents = np.stack([e[:20].mean(0), e[20:].mean(0)])
+        cohort = synth.normal(seed, "golden.dd.coh", (64, 24)).astype(np.float64)
+        scores = synth.normal(seed, "golden.dd.s", (60, 3)).astype(np.float32)
+        scores[:25, 0] += 1.5; scores[25:45, 2] += 1.5; scores[45:, 1] += 1.5
+        segs = [{"start": 0.0, "end": 3661.2345, "speaker": "S0"}, {"start": 59.9996, "end": 61.5, "speaker": "S1"}]
+        with tempfile.TemporaryDirectory() as td:
+            rdd.save_srt(os.path.join(td, "a.srt"), segs)
+            rdd.save_csv(os.path.join(td, "a.csv"), segs)
+            rdd.save_json(os.path.join(td, "a.json"), segs, ["S0", "S1"])
+            texts = {k: open(os.path.join(td, f"a.{k}"), encoding="utf-8").read() for k in ("srt", "csv", "json")}
+        dd.append(dict(seed=seed, embs=e, centers=cents, cohort=cohort, whiten=rdd.whiten_l2(e), asnorm=rdd.asnorm_scores(e, cents, cohort, topk=20),
+                       scores=scores, viterbi=rdd.viterbi_hmm(scores, alpha=0.9), viterbi_sticky=rdd.viterbi_hmm(scores), segments=segs, texts=texts))
+    out["diar_diag"] = dd
 
     for name, payload in out.items():
         with open(os.path.join(HERE, f"{name}.json"), "w") as f:

@@ -162,3 +162,21 @@ def test_embedding_callers_edge_cases():
     seg = [asd.Segment(0.0, 1.3)]
     assert asd.scd_split_segments(np.zeros(32000, np.float32), 16000, seg, encode=_fake_encode) == seg
     assert asd.frame_reassign(y, 16000, [], [], np.zeros((0, 192)), encode=_fake_encode) == []
+
+
+def test_diar_diag_score_helpers_match_reference(golden_dir, tmp_path):
+    from speech_diarization_amd import diar_diag as dd
+    for case in _load(golden_dir, "diar_diag"):
+        e, cents, cohort = (np.asarray(case[k], dtype=np.float64) for k in ("embs", "centers", "cohort"))
+        w = dd.whiten_l2(e)
+        # whitening is defined up to the eigenvector basis of equal eigenvalues; the Gram matrix is basis-free
+        assert np.allclose(w @ w.T, np.asarray(case["whiten"]) @ np.asarray(case["whiten"]).T, atol=1e-6)
+        assert np.allclose(dd.asnorm_scores(e, cents, cohort, topk=20), case["asnorm"], atol=1e-9)
+        scores = np.asarray(case["scores"], dtype=np.float32)
+        assert dd.viterbi_hmm(scores, alpha=0.9).tolist() == case["viterbi"]
+        assert dd.viterbi_hmm(scores).tolist() == case["viterbi_sticky"]
+        dd.save_srt(tmp_path / "a.srt", case["segments"])
+        dd.save_csv(tmp_path / "a.csv", case["segments"])
+        dd.save_json(tmp_path / "a.json", case["segments"], ["S0", "S1"])
+        for k in ("srt", "csv", "json"):
+            assert (tmp_path / f"a.{k}").read_text(encoding="utf-8") == case["texts"][k]
