@@ -214,62 +214,45 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16_kernel(const sd_conv_arg
   sd_store_tile<TO, BM, BN, 256>(p, Cs, LDC, m0, n0, tid, vec);
 }
 
-// ------------------------------------------------------------------------------------------
-// f16 activations: LDS-DMA ("glds") pipeline.  At the f16 MFMA rate one K step is ~0.2 us of
-// matrix work per wave, so (a) staging through VGPRs + ds_write_b128 makes the LDS write port
-// the bottleneck (the 128x128 kernel above measures 400-700 TFLOP/s), and (b) a fetch issued
-// one step ahead cannot cover an L2/HBM round trip.  Here global_load_lds_dwordx4 writes the
-// operand tiles straight into a 3-stage LDS ring, two K steps ahead, with a counted
-// s_waitcnt vmcnt + raw s_barrier per step (never vmcnt(0) in the loop).
-//
-// Tile 256x128, 8 waves (4x2) of 64x64, BK = 64 halfs; a stage is [256+128 rows][128 bytes],
-// unpadded because one LDS-DMA wave-instruction writes 64 lanes x 16 B = 8 whole rows linearly.
-// Bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle applied on
-// the SOURCE side (each lane fetches the 16-byte chunk that belongs in its physical slot) and
-// again on the read: physical slot = logical slot ^ ((row >> 1) & 7); rows 2j, 2j+1 share a
-// 256-byte bank row, so 16 consecutive rows at one logical slot land on 16 distinct slots.
-constexpr int GBM = 256;
-constexpr int GBN = 128;
-constexpr int GROW = BK * 2;                       // bytes per LDS row (128)
-constexpr int GSTAGE = (GBM + GBN) * GROW;         // 49152 bytes
-constexpr int GNST = 3;
-constexpr int GRING_BYTES = GNST * GSTAGE;         // 147456
-constexpr int GLDS_BYTES = GRING_BYTES;
-constexpr int GLDS_PER_STEP = 6;                   // LDS-DMA instructions per thread per K step
-constexpr int GTHREADS = 512;                      // 8 waves: 4 (M) x 2 (N) of 64x64
-static_assert(GBM * GBN * 4 <= GRING_BYTES, "C tile must fit in the ring");
-
 #ifdef SD_STAMP
-// diagnostic build only (build_native.py --stamp): per-workgroup timeline in 10 ns ticks
+// diagnostic build only (build_native.py --stamp): per-workgroup cycle counters, read by tools/stamp_t256.py
 __device__ unsigned long long sd_stamp_buf[8192 * 8];
-#define SD_STAMP_AT(i) do { if (tid == 0) stamp_[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define SD_STAMP_AT(i) do { } while (0)
 #endif
 
 #define SD_GLDS16(gptr, lptr)                                                              \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),  \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-// Measured (in-kernel stamps, tools/stamp_probe.py): a K step takes ~1.2 us against 0.43 us of MFMA
-// work; what paces it is the CU's operand ingest (~41 GB/s per CU, L2-resident panels), so this
-// 256x128 tile tops out near 0.9 PFLOP/s.  A ninth wave touching the lines six steps ahead (an
-// L2 prefetcher with its own vmcnt) was tried and made every step slower; the next lever is a
-// 256x256 tile (half the bytes per flop), not more bytes in flight.
-template <typename TO>
-__global__ __launch_bounds__(GTHREADS, 2) void conv_gemm_f16_glds_kernel(const sd_conv_args p, const int vec) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+// ------------------------------------------------------------------------------------------
+// 256x256 tile for the large square convs, fed by LDS-DMA (global_load_lds_dwordx4 writes the operand
+// tiles straight into an LDS ring, no VGPR staging).  What paces every f16 variant is the CU's
+// vector-memory path (~17 B/clk = 41 GB/s per CU of operand ingest, measured with in-kernel cycle
+// counters: tools/stamp_t256.py), so the lever is bytes per flop, and this tile has half those of the
+// 128x128 kernel above.  (A 256x128 LDS-DMA variant and a ninth "L2 prefetch" wave were tried and
+// dropped: 800 vs 864 TFLOP/s on 3072x3072, and slower, respectively.)  8 waves as 2 (M) x 4 (N), each
+// 128x64 = 4x2 MFMA tiles (128 accumulator registers); K step 32 halfs, i.e. 64-byte LDS rows,
+// [512 rows] = 32 KB per stage, a 4-stage LDS-DMA ring (three K steps in flight), counted vmcnt
+// + raw barrier per step.  Swizzle for 64-byte rows: four rows share a 256-byte bank row, so
+// physical slot = logical slot ^ ((row >> 2) & 3) puts 16 consecutive rows on 16 distinct slots.
+// The 256x256 f32 C tile does not fit LDS: the epilogue runs once per 128-row half.
+constexpr int TBM = 256;
+constexpr int TBN = 256;
+constexpr int TBK = 32;                            // halfs
+constexpr int TROW = TBK * 2;                      // 64 bytes
+constexpr int TSTAGE = (TBM + TBN) * TROW;         // 32768
+constexpr int TNST = 4;
+constexpr int TLDS_BYTES = TNST * TSTAGE;          // 131072
+static_assert((TBM / 2) * TBN * 4 <= TLDS_BYTES, "half C tile must fit in the ring");
 
+template <typename TO>
+__global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;
-#ifdef SD_STAMP
-  unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-  SD_STAMP_AT(0);
   const int lane = tid & 63;
   const int wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid >> 2, wn = wid & 3;
 
-  const int n_tiles = (p.cout + GBN - 1) / GBN;
+  const int n_tiles = (p.cout + TBN - 1) / TBN;
   int wg;
   {
     const int nwg = gridDim.x, b = blockIdx.x;
@@ -278,42 +261,38 @@ __global__ __launch_bounds__(GTHREADS, 2) void conv_gemm_f16_glds_kernel(const s
   }
   const int tile_n = wg % n_tiles;
   const int tile_m = wg / n_tiles;
-  const int m0 = tile_m * GBM, n0 = tile_n * GBN;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
-  // staging role: thread (r0 = tid >> 3, ps = tid & 7) fills physical slot ps of rows r0 + 64 i;
-  // a wave-instruction therefore writes rows 8w .. 8w+7 (+64 i) = 1 KB of contiguous LDS.
-  const int r0 = tid >> 3;
-  const int ps = tid & 7;
-  int a_seg[4], a_t[4], a_ls[4];
-  const _Float16* aptr[4];
+  // staging role: thread (r0 = tid >> 2, ps = tid & 3) fills physical slot ps of A rows r0, r0+128 and of
+  // B rows r0, r0+128; one wave-instruction writes 16 whole rows (1 KB) of LDS
+  const int r0 = tid >> 2;
+  const int ps = tid & 3;
+  int a_seg[2], a_t[2], a_ls[2];
+  const _Float16* aptr[2];
   const _Float16* wptr[2];
   const int ktot = p.taps * p.cin_pad;
   const _Float16* W = static_cast<const _Float16*>(p.w);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = r0 + 64 * i;
+  for (int i = 0; i < 2; ++i) {
+    const int row = r0 + 128 * i;
+    const int ls = (ps ^ ((row >> 2) & 3)) * 8;    // logical k offset (halfs) that belongs in this lane's slot
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
     const int seg = (m / p.T) * p.T;
     a_seg[i] = seg;
     a_t[i] = m - seg;
-    a_ls[i] = (ps ^ ((row >> 1) & 7)) * 8;     // logical k offset (halfs) this lane fetches for that row
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = r0 + 64 * i;
+    a_ls[i] = ls;
     int n = n0 + row;
     n = n < p.cout ? n : p.cout - 1;
-    wptr[i] = W + (size_t)n * ktot + (ps ^ ((row >> 1) & 7)) * 8;
+    wptr[i] = W + (size_t)n * ktot + ls;
   }
-  const int nk = p.taps * (p.cin_pad / BK);
+  const int nk = p.taps * (p.cin_pad / TBK);
   const int half = p.taps / 2;
   const _Float16* X = static_cast<const _Float16*>(p.x) + p.a_col0;
-
   auto set_tap = [&](int tap) {
     const int delta = (tap - half) * p.dil;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
       int tt = a_t[i] + delta;
       tt = tt < 0 ? -tt : tt;
       tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
@@ -322,122 +301,156 @@ __global__ __launch_bounds__(GTHREADS, 2) void conv_gemm_f16_glds_kernel(const s
   };
   int ld_tap = 0, ld_c0 = 0;
   set_tap(0);
-  // wave-uniform LDS destinations of this wave's DMA pieces inside a stage
-  const int dst_a = (wid * 8) * GROW;                 // + 64*i rows
-  const int dst_b = GBM * GROW + (wid * 8) * GROW;
-  auto issue = [&](int stage) {
-    char* base = smem_raw + stage * GSTAGE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = ld_c0 + a_ls[i];
-      SD_GLDS16(aptr[i] + (col < p.cin ? col : 0), base + dst_a + i * 64 * GROW);
+  const int dst_a = (wid * 16) * TROW;                  // + 128*i rows
+  const int dst_b = TBM * TROW + (wid * 16) * TROW;
+  // DMA piece g of a K step: g = 0, 1 -> A rows r0, r0 + 128; g = 2, 3 -> B rows r0, r0 + 128
+  auto piece = [&](char* base, int g) {
+    if (g < 2) {
+      const int col = ld_c0 + a_ls[g];
+      SD_GLDS16(aptr[g] + (col < p.cin ? col : 0), base + dst_a + g * 128 * TROW);
+    } else {
+      SD_GLDS16(wptr[g - 2], base + dst_b + (g - 2) * 128 * TROW);
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      SD_GLDS16(wptr[i], base + dst_b + i * 64 * GROW);
-      wptr[i] += BK;
-    }
-    ld_c0 += BK;
+  };
+  auto advance = [&]() {
+    wptr[0] += TBK;
+    wptr[1] += TBK;
+    ld_c0 += TBK;
     if (ld_c0 >= p.cin_pad) {
       ld_c0 = 0;
       ++ld_tap;
       if (ld_tap < p.taps) set_tap(ld_tap);
     }
   };
-
-  f32x16 acc[2][2];
+  auto issue = [&](int stage) {
+    char* base = smem_raw + stage * TSTAGE;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int g = 0; g < 4; ++g) piece(base, g);
+    advance();
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // fragment addressing: lane (r, h) reads logical slot 2*kk + h of its row, swizzled
   const int fr = lane & 31, fh = lane >> 5;
-  int a_off[2], b_off[2], a_sw[2], b_sw[2];
+  int a_off[4], a_sw[4], b_off[2], b_sw[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 128 + i * 32 + fr;
+    a_off[i] = ra * TROW;
+    a_sw[i] = (ra >> 2) & 3;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int ra = wm * 64 + i * 32 + fr;
     const int rb = wn * 64 + i * 32 + fr;
-    a_off[i] = ra * GROW;            a_sw[i] = (ra >> 1) & 7;
-    b_off[i] = GBM * GROW + rb * GROW; b_sw[i] = (rb >> 1) & 7;
+    b_off[i] = TBM * TROW + rb * TROW;
+    b_sw[i] = (rb >> 2) & 3;
   }
-  auto mma_step = [&](const char* st, int kk) {
-    const int ls = 2 * kk + fh;
-    const h8 a0 = *reinterpret_cast<const h8*>(st + a_off[0] + ((ls ^ a_sw[0]) << 4));
-    const h8 a1 = *reinterpret_cast<const h8*>(st + a_off[1] + ((ls ^ a_sw[1]) << 4));
-    const h8 b0 = *reinterpret_cast<const h8*>(st + b_off[0] + ((ls ^ b_sw[0]) << 4));
-    const h8 b1 = *reinterpret_cast<const h8*>(st + b_off[1] + ((ls ^ b_sw[1]) << 4));
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-  };
 
-  SD_STAMP_AT(1);
-  issue(0);
-  if (nk > 1) issue(1);
-  int st_rd = 0, st_wr = 2;
+#ifdef SD_STAMP
+  unsigned long long tacc[4] = {0, 0, 0, 0};   // wave 0's cycles in: DMA wait, barrier, DMA issue, LDS reads + MFMA
+#define SD_TSEG(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; } while (0)
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#else
+#define SD_TSEG(i) do { } while (0)
+#endif
+  for (int s0 = 0; s0 < TNST - 1 && s0 < nk; ++s0) issue(s0);
+  int st_rd = 0, st_wr = TNST - 1;
+  const bool early = __builtin_amdgcn_readfirstlane(wid) < 4;
   for (int kt = 0; kt < nk; ++kt) {
-    // retire this step's stage: everything but the youngest K step's DMA pieces must have landed
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    SD_TSEG(3);
+    // 4 DMA pieces per thread per step; the two youngest steps may stay in flight
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // all waves' pieces of stage st_rd landed; stage st_wr is no longer being read
-    if (kt == 0) SD_STAMP_AT(2);
-    if (kt + 2 < nk) issue(st_wr);
-    const char* st = smem_raw + st_rd * GSTAGE;
+    SD_TSEG(0);
+    __builtin_amdgcn_s_barrier();
+    SD_TSEG(1);
+    // SIMD partners (waves w and w+4) are staggered: the first half issues its DMA pieces right after
+    // the barrier, the second half only after its first MFMA group, so one partner's ~100-cycle-per-piece
+    // DMA issue runs under the other's MFMAs instead of all eight waves issuing, then all computing
+    // SIMD partners (waves w and w+4) are staggered: the first half issues its DMA pieces right after
+    // the barrier, the second half after its first MFMA group, so one partner's DMA issue (~100 cycles
+    // per piece: the CU's vector-memory path, not the instruction count, paces it) runs under the
+    // other's MFMAs.  Spreading single pieces between MFMA groups of the SAME wave was slower.
+    const bool more = kt + TNST - 1 < nk;
+    if (more && early) issue(st_wr);
+    SD_TSEG(2);
+    const char* st = smem_raw + st_rd * TSTAGE;
+    h8 fa[2][4], fb[2][2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) mma_step(st, kk);
-    st_rd = st_rd == GNST - 1 ? 0 : st_rd + 1;
-    st_wr = st_wr == GNST - 1 ? 0 : st_wr + 1;
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ls = 2 * kk + fh;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[kk][i] = *reinterpret_cast<const h8*>(st + a_off[i] + ((ls ^ a_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[kk][j] = *reinterpret_cast<const h8*>(st + b_off[j] + ((ls ^ b_sw[j]) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+    if (more && !early) issue(st_wr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+    st_rd = st_rd == TNST - 1 ? 0 : st_rd + 1;
+    st_wr = st_wr == TNST - 1 ? 0 : st_wr + 1;
   }
-  static_assert(GLDS_PER_STEP == 6, "the counted vmcnt above assumes 6 LDS-DMA pieces per thread per K step");
-  SD_STAMP_AT(3);
-  __syncthreads();   // every wave is done with the ring before it becomes the C tile
+#ifdef SD_STAMP
+  SD_TSEG(3);
+  if (tid == 0 && blockIdx.x < 8192)
+    for (int i = 0; i < 4; ++i) sd_stamp_buf[blockIdx.x * 8 + i] = tacc[i];
+#endif
+  __syncthreads();
 
-  // ---- epilogue: raw accumulators -> LDS C tile [256][128] f32 -> sd_store_tile (sd_epilogue.h)
+  // ---- epilogue, one 128-row half at a time: the owning waves stage raw accumulators as a
+  // [128][256] f32 tile in the ring, then all 512 threads run sd_store_tile on it
   float* Cs = reinterpret_cast<float*>(smem_raw);
   const int hrow = (lane >> 5) * 4;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int cl = wn * 64 + ni * 32 + (lane & 31);
+  for (int hm = 0; hm < 2; ++hm) {
+    if (wm == hm) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+      for (int ni = 0; ni < 2; ++ni) {
+        const int cl = wn * 64 + ni * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-        Cs[rl * GBN + cl] = acc[mi][ni][r];
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = mi * 32 + (r & 3) + 8 * (r >> 2) + hrow;
+            Cs[rl * TBN + cl] = acc[mi][ni][r];
+          }
+        }
       }
     }
+    __syncthreads();
+    sd_store_tile<TO, TBM / 2, TBN, 512>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
+    __syncthreads();
   }
-  __syncthreads();
-  SD_STAMP_AT(4);
-  sd_store_tile<TO, GBM, GBN, 512>(p, Cs, GBN, m0, n0, tid, vec);
-  SD_STAMP_AT(5);
-#ifdef SD_STAMP
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  SD_STAMP_AT(6);
-  if (tid == 0 && blockIdx.x < 8192)
-    for (int i = 0; i < 8; ++i) sd_stamp_buf[blockIdx.x * 8 + i] = stamp_[i];
-#endif
 }
 
 template <typename TO>
-int launch_glds(const sd_conv_args* a, int vec, hipStream_t stream) {
-  const long tiles_m = (a->M + GBM - 1) / GBM;
-  const long tiles_n = (a->cout + GBN - 1) / GBN;
-  auto kern = conv_gemm_f16_glds_kernel<TO>;
+int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
+  const long tiles_m = (a->M + TBM - 1) / TBM;
+  const long tiles_n = (a->cout + TBN - 1) / TBN;
+  auto kern = conv_gemm_f16_t256_kernel<TO>;
   static bool attr_set = false;
   if (!attr_set) {
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS_BYTES));
+    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES));
     attr_set = true;
   }
   {
     SdProfScope prof(SD_PROF_CONV_GEMM, stream, 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(GTHREADS), GLDS_BYTES, stream, *a, vec);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), TLDS_BYTES, stream, *a, vec);
   }
-  SD_CHECK_LAUNCH("conv_gemm_f16_glds_kernel");
+  SD_CHECK_LAUNCH("conv_gemm_f16_t256_kernel");
   return SD_OK;
 }
 
@@ -500,15 +513,19 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
     if (a->tee_add) vec = vec && a->ld_ta % 8 == 0 && a->ta_col0 % 8 == 0 && sd_aligned16(a->tee_add);
   }
   const bool xa = a->x_dtype == SD_DT_F16, ya = a->y_dtype == SD_DT_F16;
-  // Kernel choice, measured per shape on MI355X (tools/probe_conv.py, B*T = 205 824 rows): the 256x128
-  // LDS-DMA ring wins only on the big square MFA conv (3072x3072: 800 vs 785 TFLOP/s); the
-  // register-staged 128x128 kernel with two workgroups per CU is faster everywhere else
-  // (1024x1024: 588 vs 541, Res2Net 128x384: 327 vs 275, 128->3072: 205 vs 185).
-  // SD_F16_GLDS=0 / 1 forces one or the other for A/B runs.
-  static const int force_glds = [] { const char* e = getenv("SD_F16_GLDS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  // Kernel choice, measured per shape on MI355X (tools/probe_conv.py, B*T = 205 824 rows): the 256x256
+  // LDS-DMA kernel wins on the big square MFA conv (3072x3072: 864 vs 785 TFLOP/s) and ties on
+  // 1024x1024 (584 vs 588); the register-staged 128x128 kernel with two workgroups per CU is faster
+  // on the narrow layers (Res2Net 128x384: 327, 128->3072: 205, 3072->128: 524).
+  // SD_F16_KERNEL=reg|t256 forces one kernel for A/B runs.
+  static const int forced = [] {
+    const char* e = getenv("SD_F16_KERNEL");
+    if (!e) return -1;
+    return e[0] == 'r' ? 0 : e[0] == 't' ? 2 : -1;
+  }();
   const bool big = a->cout >= 2048 && (long)a->taps * a->cin >= 2048;
-  const bool use_glds = force_glds < 0 ? big : force_glds == 1;
-  if (xa && use_glds) return ya ? launch_glds<_Float16>(a, vec, stream) : launch_glds<float>(a, vec, stream);
+  const int choice = forced >= 0 ? forced : (big ? 2 : 0);
+  if (xa && choice == 2) return ya ? launch_t256<_Float16>(a, vec, stream) : launch_t256<float>(a, vec, stream);
   if (xa && ya) return launch<_Float16, _Float16>(a, vec, stream);
   if (xa && !ya) return launch<_Float16, float>(a, vec, stream);
   if (!xa && ya) return launch<float, _Float16>(a, vec, stream);
