@@ -74,8 +74,8 @@ int sd_profile_read(int kind, double* ms, long long* launches, double* work);
 typedef struct sd_fbank_plan sd_fbank_plan;
 
 /* window: host [n_fft] (must satisfy w[k] == w[n_fft-k], true for periodic
- * Hann/Hamming); mel_fb: host [n_fft/2+1][n_mels] row-major, at most 2 non-zero
- * filters per frequency bin (triangular banks).  Only n_fft=400, hop=160 (25 ms
+ * Hann/Hamming); mel_fb: host [n_fft/2+1][n_mels] row-major, n_mels <= 80 (any filter
+ * shapes: the mel product is dense on the matrix cores).  Only n_fft=400, hop=160 (25 ms
  * / 10 ms at 16 kHz, [REF speech_encode.py:14-15]) is implemented.  Allocates
  * the device-side basis / filter tables. */
 sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, int hop,

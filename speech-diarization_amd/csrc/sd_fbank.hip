@@ -13,12 +13,21 @@
 // (x[400] := 0 for k = 0, Cb[200] halved), i.e. two GEMMs  [bins x K] * [K x frames]
 // that run on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 fma chain).
 // The basis is a host-computed table; a wave owns 32 consecutive frames, keeps their
-// sample span in LDS (each sample is fetched from HBM once per tile, 4.5 % overlap),
-// forms the folded operands on the fly, and accumulates |X|^2 into the mel bins kept
-// in LDS.  Tiles are flat over (utterance, frame) so no lane idles on T = 201.
+// sample span in LDS (each sample is fetched from HBM once per tile, 4.5 % overlap) and
+// forms the folded operands on the fly.  The mel energies are a third product on the same
+// matrix cores, mel[m][frame] += W[bin][m] * |X[bin][frame]|^2, fed straight from the DFT
+// accumulators (no scatter through LDS).  Tiles are flat over (utterance, frame) so no lane
+// idles on T = 201.
 //
 // LDS: sample spans are skewed by one word per 160 samples so that the 32 frames of
-// a tile (stride 160 words = 0 mod 32 banks) hit 32 distinct banks.
+// a tile (stride 160 words = 0 mod 32 banks) hit 32 distinct banks; the six K chunks of a
+// frequency tile are unrolled so every operand read is a ds_read with an immediate offset.
+//
+// Round-1 measurements that shaped it (tools/stamp_fbank.py, in-kernel cycle counters): a per-lane
+// read-modify-write scatter of |X|^2 into LDS mel accumulators took 41 % of the kernel (LDS
+// float adds no better) -> MFMA mel; one-chunk-ahead basis prefetch stalled on L2 -> two register
+// stages; per-lane address arithmetic for the skewed reads cost as much issue time as the
+// MFMAs -> immediate offsets.  4.9 -> 3.0 ms per 5000 segments.
 #include "sd_common.h"
 #include <cmath>
 #include <cstdlib>
@@ -40,14 +49,15 @@ constexpr int XS_W = 5760;   // per-wave sample LDS, floats
 constexpr int MELP = 81;     // mel accumulator row stride
 constexpr int MAX_MELS = 80;
 constexpr int CHUNK_FLOATS = KC * 64;  // [KC][cos 32 | sin 32]
+constexpr int MELW_COLS = 96;                 // mel filters padded to three 32-wide MFMA tiles
+constexpr int MELW_FLOATS = NBT * 16 * 2 * MELW_COLS;
 constexpr int LDS_FLOATS = WAVES * XS_W + WAVES * FT * MELP + 2 * CHUNK_FLOATS;
 
-struct MelEntry { int i0, i1; float w0, w1; };
 
 struct FbankArgs {
   const float* wav; int B; int n; int T;
   const float* basis;      // [NBT][KP][64]
-  const MelEntry* mel_tab; // [NBT*32]
+  const float* melw;       // [NBT][16][2][MELW_COLS]: mel weights in the order the MFMA accumulators hold the bins
   int n_mels; int pad_mode; int log_mode; float log_eps;
   float* out; int ld_out;
   int* maxbuf;             // [B] ordered-int keys of the utterance max
@@ -62,9 +72,20 @@ __device__ __forceinline__ float key_f32(int k) {
   return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF);
 }
 
+#ifdef SD_STAMP
+__device__ unsigned long long sd_fb_stamp_buf[8192 * 8];
+#define FB_TSEG(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tacc[i] += now_ - tprev; tprev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FB_TSEG(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const FbankArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#ifdef SD_STAMP
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
   float* xs = smem + wid * XS_W;
   float* macc = smem + WAVES * XS_W + wid * FT * MELP;
   float* bs = smem + WAVES * XS_W + WAVES * FT * MELP;
@@ -102,38 +123,35 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const FbankArgs p)
   int offB = lenA + lenA / HOP + 1;
   offB = ((offB + 31) & ~31) + (nfA & 31);
   {
-    const float* src = p.wav + (size_t)bA * p.n;
-    const int s0 = tA * HOP - NFFT / 2;
-    for (int rel = lane; rel < lenA; rel += 64) {
-      int s = s0 + rel;
-      float v;
-      if (p.pad_mode == SD_PAD_REFLECT) {
-        s = s < 0 ? -s : s;
-        s = s >= p.n ? 2 * (p.n - 1) - s : s;
-        v = src[s];
-      } else {
-        v = (s >= 0 && s < p.n) ? src[s] : 0.f;
-      }
-      xs[rel + rel / HOP] = v;
-    }
-    if (nfB > 0) {
-      const float* srcB = p.wav + (size_t)(bA + 1) * p.n;
-      const int lenB = (nfB - 1) * HOP + NFFT;
-      for (int rel = lane; rel < lenB; rel += 64) {
-        int s = rel - NFFT / 2;
-        float v;
-        if (p.pad_mode == SD_PAD_REFLECT) {
-          s = s < 0 ? -s : s;
-          s = s >= p.n ? 2 * (p.n - 1) - s : s;
-          v = srcB[s];
-        } else {
-          v = (s >= 0 && s < p.n) ? srcB[s] : 0.f;
+    // 8 independent loads in flight per lane, then 8 LDS writes (a one-load-per-iteration loop pays a
+    // full memory round trip 88 times per tile)
+    auto stage_span = [&](const float* src, int s0, int len, int off) {
+      for (int rel0 = lane; rel0 < len; rel0 += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rel = rel0 + 64 * u;
+          int sidx = s0 + rel;
+          bool ok = rel < len;
+          if (p.pad_mode == SD_PAD_REFLECT) {
+            sidx = sidx < 0 ? -sidx : sidx;
+            sidx = sidx >= p.n ? 2 * (p.n - 1) - sidx : sidx;
+          } else {
+            ok = ok && sidx >= 0 && sidx < p.n;
+          }
+          v[u] = ok ? src[ok ? sidx : 0] : 0.f;
         }
-        xs[offB + rel + rel / HOP] = v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rel = rel0 + 64 * u;
+          if (rel < len) xs[off + rel + rel / HOP] = v[u];
+        }
       }
-    }
+    };
+    stage_span(p.wav + (size_t)bA * p.n, tA * HOP - NFFT / 2, lenA, 0);
+    if (nfB > 0) stage_span(p.wav + (size_t)(bA + 1) * p.n, -NFFT / 2, (nfB - 1) * HOP + NFFT, offB);
   }
-  for (int i = lane; i < FT * MELP; i += 64) macc[i] = 0.f;
+  FB_TSEG(0);   // tile bookkeeping + sample staging
 
   const int j = lane & 31;   // frame within tile (MFMA column)
   const int h = lane >> 5;   // k slot / row half
@@ -143,74 +161,120 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const FbankArgs p)
   else base = 0;             // idle lane: reads something harmless, never stored
 
   // ---- basis chunk pipeline (all 4 waves share the staged chunk)
-  f32x4 pre[3];
-  auto bload = [&](int ch) {
+  // two register stages: the chunk after next is already in flight while this one is multiplied
+  // (a chunk is only 34 MFMAs = 2176 cycles, less than an L2 round trip under load)
+  struct Pre { f32x4 v[3]; };
+  Pre preA, preB;
+  auto bload = [&](Pre& r, int ch) {
     const f32x4* g = reinterpret_cast<const f32x4*>(p.basis + (size_t)ch * CHUNK_FLOATS);
-    pre[0] = g[tid];
-    pre[1] = g[tid + 256];
-    if (tid < CHUNK_FLOATS / 4 - 512) pre[2] = g[tid + 512];
+    r.v[0] = g[tid];
+    r.v[1] = g[tid + 256];
+    if (tid < CHUNK_FLOATS / 4 - 512) r.v[2] = g[tid + 512];
   };
-  auto bstore = [&](int buf) {
+  auto bstore = [&](const Pre& r, int buf) {
     f32x4* d = reinterpret_cast<f32x4*>(bs + buf * CHUNK_FLOATS);
-    d[tid] = pre[0];
-    d[tid + 256] = pre[1];
-    if (tid < CHUNK_FLOATS / 4 - 512) d[tid + 512] = pre[2];
+    d[tid] = r.v[0];
+    d[tid + 256] = r.v[1];
+    if (tid < CHUNK_FLOATS / 4 - 512) d[tid + 512] = r.v[2];
   };
+  constexpr int NCH_TOTAL = NBT * NCHUNK;
+  static_assert(NCHUNK % 2 == 0, "the chunk loop is unrolled by two register stages");
 
-  bload(0);
-  bstore(0);
+  bload(preA, 0);
+  bstore(preA, 0);
+  bload(preB, 1);      // chunk 1 -> stored at the end of chunk 0
+  bload(preA, 2);      // chunk 2 -> stored at the end of chunk 1
   __syncthreads();
-  int cur = 0;
+
+  // mel energies accumulate on the matrix cores too: mel[m][frame] += W[bin][m] * |X[bin][frame]|^2 with the
+  // power spectrum taken straight from the DFT accumulators as the B operand (lane half h supplies bin
+  // 32q + (s&3) + 8(s>>2) + 4h at step s) — no per-lane scatter through LDS
+  f32x16 mel[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mel[t][r] = 0.f;
 
   for (int q = 0; q < NBT; ++q) {
     f32x16 accRe, accIm;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accRe[r] = 0.f; accIm[r] = 0.f; }
+    // this tile's mel weights: 48 coalesced dword loads issued now, consumed after the DFT of the tile
+    float mw[16][3];
+    {
+      const float* wq = p.melw + ((size_t)(q * 16) * 2 + h) * MELW_COLS + j;
+#pragma unroll
+      for (int sidx = 0; sidx < 16; ++sidx)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) mw[sidx][t] = wq[(size_t)sidx * 2 * MELW_COLS + 32 * t];
+    }
 
-    for (int c = 0; c < NCHUNK; ++c) {
+    // The six chunks of a tile are unrolled, so every k below is a compile-time constant and each operand
+    // read is a ds_read with an immediate offset from one of three per-lane bases (no address VALU in the
+    // loop): lane half h handles k = k0 + h; x[k] sits at pa[skew(k0)], x[400 - k] at pb1/pb2[skew(400 - k0)]
+    // (the skewed offset steps by 2 instead of 1 where 400 - k0 is exactly 160 or 320).
+    const float* pa = xs + base + h;
+    const float* pb1 = xs + base - h;
+    const float* pb2 = xs + base - 2 * h;
+    auto chunk = [&](const int c, Pre& st) {
+      // `st` holds chunk ch+1 (written to the other LDS stage at the end), then refills with chunk ch+3
       const int ch = q * NCHUNK + c;
-      const bool more = ch + 1 < NBT * NCHUNK;
-      if (more) bload(ch + 1);
-      const float* bcur = bs + cur * CHUNK_FLOATS + h * 64 + j;
-      const int kbase = c * KC + h;
+      const int buf = c & 1;                                  // NCHUNK is even: the stage parity restarts with each tile
+      const float* bcur = bs + buf * CHUNK_FLOATS + h * 64 + j;
+      // software pipeline inside the chunk: the LDS operands of step kk + PD are requested right before
+      // the two MFMAs of step kk (the wave is alone on its SIMD; left to itself the scheduler puts an LDS
+      // round trip in front of every MFMA pair).  sched_barrier pins that order.
+      constexpr int PD = 4;
+      float xa[KC / 2], xb[KC / 2], cb[KC / 2], sb[KC / 2];
+      auto fetch = [&](const int kk) {
+        const int k0 = c * KC + 2 * kk;
+        const int kb0 = NFFT - k0;
+        const int ka_s = k0 + (k0 >= HOP) + (k0 >= 2 * HOP);
+        const int kb_s = kb0 + (kb0 >= HOP) + (kb0 >= 2 * HOP);
+        xa[kk] = pa[ka_s];
+        const float t = (kb0 == HOP || kb0 == 2 * HOP) ? pb2[kb_s] : pb1[kb_s];
+        xb[kk] = (k0 == 0 && h == 0) ? 0.f : t;
+        cb[kk] = bcur[kk * 128];
+        sb[kk] = bcur[kk * 128 + 32];
+      };
+#pragma unroll
+      for (int kk = 0; kk < PD; ++kk) fetch(kk);
 #pragma unroll
       for (int kk = 0; kk < KC / 2; ++kk) {
-        const int k = kbase + 2 * kk;
-        const int kb = NFFT - k;
-        const int ka_s = k + (k >= HOP) + (k >= 2 * HOP);
-        const int kb_s = kb + (kb >= HOP) + (kb >= 2 * HOP);
-        const float xa = xs[base + ka_s];
-        float xb = xs[base + kb_s];
-        xb = (k == 0) ? 0.f : xb;
-        const float cb = bcur[kk * 128];
-        const float sb = bcur[kk * 128 + 32];
-        accRe = __builtin_amdgcn_mfma_f32_32x32x2f32(cb, xa + xb, accRe, 0, 0, 0);
-        accIm = __builtin_amdgcn_mfma_f32_32x32x2f32(sb, xa - xb, accIm, 0, 0, 0);
+        if (kk + PD < KC / 2) fetch(kk + PD);
+        accRe = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[kk], xa[kk] + xb[kk], accRe, 0, 0, 0);
+        accIm = __builtin_amdgcn_mfma_f32_32x32x2f32(sb[kk], xa[kk] - xb[kk], accIm, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (more) bstore(cur ^ 1);
+      FB_TSEG(1);   // operand reads + MFMA
+      if (ch + 1 < NCH_TOTAL) bstore(st, buf ^ 1);
+      if (ch + 3 < NCH_TOTAL) bload(st, ch + 3);
       __syncthreads();
-      cur ^= 1;
+      FB_TSEG(2);   // basis stage write + barrier
+    };
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c += 2) {
+      chunk(c, preB);
+      chunk(c + 1, preA);
     }
 
-    // ---- |X|^2 -> mel bins. Lane holds bins 32q + (r&3) + 8(r>>2) + 4h of frame j.
-    // The two lane halves own different bins of the same frame and may hit the same
-    // filter, so they take turns (fixed order, deterministic).
-    float* mrow = macc + j * MELP;
+    // ---- |X|^2 -> mel: 16 x 3 MFMAs per frequency tile
 #pragma unroll
-    for (int turn = 0; turn < 2; ++turn) {
-      if (h == turn) {
+    for (int sidx = 0; sidx < 16; ++sidx) {
+      const float pw = accRe[sidx] * accRe[sidx] + accIm[sidx] * accIm[sidx];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int bin = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const MelEntry e = p.mel_tab[bin];
-          const float pw = accRe[r] * accRe[r] + accIm[r] * accIm[r];
-          if (e.i0 >= 0) mrow[e.i0] += e.w0 * pw;
-          if (e.i1 >= 0) mrow[e.i1] += e.w1 * pw;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();  // keep the two turns' LDS updates in program order
+      for (int t = 0; t < 3; ++t) mel[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mw[sidx][t], pw, mel[t], 0, 0, 0);
     }
+    FB_TSEG(3);     // |X|^2 -> mel
   }
+  // mel tile rows -> LDS [frame][mel] for the log / max / coalesced-store passes below
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < p.n_mels) macc[j * MELP + m] = mel[t][r];
+    }
   __syncthreads();
 
   // ---- log + utterance max; lane (j, h) takes half of the mel bins of frame j
@@ -235,6 +299,7 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const FbankArgs p)
     }
   }
   __syncthreads();
+  FB_TSEG(4);       // log, utterance max
   // ---- coalesced store of the tile's [nvalid][n_mels] block
   {
     const int total = nvalid * p.n_mels;
@@ -244,6 +309,11 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const FbankArgs p)
       p.out[(size_t)(rowA + jj) * p.ld_out + m] = macc[jj * MELP + m];
     }
   }
+#ifdef SD_STAMP
+  FB_TSEG(5);
+  if (tid == 0 && blockIdx.x < 8192)
+    for (int i = 0; i < 8; ++i) sd_fb_stamp_buf[blockIdx.x * 8 + i] = tacc[i];
+#endif
 }
 
 __global__ void fill_i32_kernel(int* p, int n, int v) {
@@ -286,8 +356,16 @@ struct sd_fbank_plan {
   int n_fft, hop, n_mels, pad_mode, log_mode;
   float log_eps, top_db;
   float* basis_dev;
-  MelEntry* mel_dev;
+  float* mel_dev;
 };
+
+#ifdef SD_STAMP
+extern "C" int sd_debug_read_fbank_stamps(unsigned long long* out, int n) {
+  SD_CHECK_HIP(hipDeviceSynchronize());
+  SD_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(sd_fb_stamp_buf), (size_t)n * sizeof(unsigned long long)));
+  return SD_OK;
+}
+#endif
 
 extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, int hop,
                                                const float* mel_fb, int n_mels,
@@ -320,28 +398,22 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
         row[i] = (float)cw;
         row[32 + i] = (float)sw;
       }
-  std::vector<MelEntry> tab(NBT * 32);
-  for (int bin = 0; bin < NBT * 32; ++bin) {
-    MelEntry e{-1, -1, 0.f, 0.f};
-    if (bin < NFREQ) {
-      int cnt = 0;
-      for (int m = 0; m < n_mels; ++m) {
-        const float w = mel_fb[(size_t)bin * n_mels + m];
-        if (w == 0.f) continue;
-        if (cnt == 0) { e.i0 = m; e.w0 = w; }
-        else if (cnt == 1) { e.i1 = m; e.w1 = w; }
-        else return fail(SD_ERR_UNSUPPORTED, "sd_fbank_plan_create: more than 2 non-zero mel filters on one frequency bin");
-        ++cnt;
+  // dense mel weights in accumulator order: entry [q][s][h][m] belongs to bin 32q + (s&3) + 8(s>>2) + 4h
+  std::vector<float> tab((size_t)MELW_FLOATS, 0.f);
+  for (int q = 0; q < NBT; ++q)
+    for (int sidx = 0; sidx < 16; ++sidx)
+      for (int hh = 0; hh < 2; ++hh) {
+        const int bin = 32 * q + (sidx & 3) + 8 * (sidx >> 2) + 4 * hh;
+        if (bin >= NFREQ) continue;
+        float* row = tab.data() + ((size_t)(q * 16 + sidx) * 2 + hh) * MELW_COLS;
+        for (int m = 0; m < n_mels; ++m) row[m] = mel_fb[(size_t)bin * n_mels + m];
       }
-    }
-    tab[bin] = e;
-  }
   sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr};
   hipError_t e1 = hipMalloc(&plan->basis_dev, basis.size() * sizeof(float));
-  hipError_t e2 = e1 == hipSuccess ? hipMalloc(&plan->mel_dev, tab.size() * sizeof(MelEntry)) : e1;
+  hipError_t e2 = e1 == hipSuccess ? hipMalloc(&plan->mel_dev, tab.size() * sizeof(float)) : e1;
   if (e1 == hipSuccess && e2 == hipSuccess) {
     e1 = hipMemcpy(plan->basis_dev, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice);
-    e2 = hipMemcpy(plan->mel_dev, tab.data(), tab.size() * sizeof(MelEntry), hipMemcpyHostToDevice);
+    e2 = hipMemcpy(plan->mel_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
   }
   if (e1 != hipSuccess || e2 != hipSuccess) {
     sd_set_error(SD_ERR_HIP, "sd_fbank_plan_create: device table upload failed: %s",
@@ -389,7 +461,7 @@ extern "C" int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int
   const int T = 1 + n / HOP;
   FbankArgs a;
   a.wav = wav_dev; a.B = B; a.n = n; a.T = T;
-  a.basis = plan->basis_dev; a.mel_tab = plan->mel_dev;
+  a.basis = plan->basis_dev; a.melw = plan->mel_dev;
   a.n_mels = plan->n_mels; a.pad_mode = plan->pad_mode; a.log_mode = plan->log_mode; a.log_eps = plan->log_eps;
   a.out = out_dev; a.ld_out = ld_out;
   a.maxbuf = static_cast<int*>(ws_dev);
