@@ -29,6 +29,10 @@ constexpr int LDP = BK + 4;  // padded LDS row, floats
 constexpr int LDC = BN + 4;  // padded row of the epilogue's C tile in LDS
 static_assert(BM * LDC <= 2 * (BM + BN) * LDP, "C tile must fit in the operand stage");
 
+#ifdef SD_STAMP
+__device__ unsigned long long sd_c32_stamp_buf[8192 * 4];
+#endif
+
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p, const int vec) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM][LDP]
@@ -149,6 +153,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   // and written to the other LDS stage ahead of the last group, so the part of a K step in
   // which this wave issues no MFMA is as short as possible (its SIMD partner from the other
   // resident workgroup runs the same program and tends to fall into phase with it).
+#ifdef SD_STAMP
+  unsigned long long tacc[4] = {0, 0, 0, 0};   // wave 0: MFMA groups + fragment reads, fetch issue, stage write (incl. vmcnt wait), barrier
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define C32_TSEG(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tacc[i] += now_ - tprev; tprev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define C32_TSEG(i) do { } while (0)
+#endif
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
@@ -157,16 +168,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
     Frag f0 = fread(a, b, 0);
     Frag f1 = fread(a, b, 1);
     mma(f0);
+    C32_TSEG(0);
     if (more) gload();
+    C32_TSEG(1);
     f0 = fread(a, b, 2);
     mma(f1);
     f1 = fread(a, b, 3);
     mma(f0);
+    C32_TSEG(0);
     if (more) lstore(cur ^ 1);
+    C32_TSEG(2);
     mma(f1);
+    C32_TSEG(0);
     __syncthreads();
+    C32_TSEG(3);
     cur ^= 1;
   }
+#ifdef SD_STAMP
+  if (tid == 0 && blockIdx.x < 8192)
+    for (int i = 0; i < 4; ++i) sd_c32_stamp_buf[blockIdx.x * 4 + i] = tacc[i];
+#endif
 
   // ---- epilogue: raw accumulators -> LDS C tile (the main loop's last barrier has retired every
   // read of the operand stage), then sd_store_tile applies bias / activation / BN affine and
@@ -250,6 +271,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const sd_conv_args
 }
 
 }  // namespace
+
+#ifdef SD_STAMP
+extern "C" int sd_debug_read_c32_stamps(unsigned long long* out, int n) {
+  SD_CHECK_HIP(hipDeviceSynchronize());
+  SD_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(sd_c32_stamp_buf), (size_t)n * sizeof(unsigned long long)));
+  return SD_OK;
+}
+#endif
 
 extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
   SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_f32: null args");

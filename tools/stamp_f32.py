@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Diagnostic (build_native.py --stamp): cycle shares of conv_gemm_f32_kernel's K loop, wave 0 of each workgroup."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from speech_diarization_amd import ops, _native
+cin, cout = int(sys.argv[1]), int(sys.argv[2])
+dev = torch.device("cuda", 0); T = 201; M = 1024 * T
+x = torch.randn(M, cin, device=dev); w = torch.randn(cout, cin, 1) / cin ** 0.5
+wp = ops.pack_weight(w, dev); out = torch.empty(M, cout, device=dev)
+for _ in range(2):
+    ops.conv1d_cl(x, wp, T, cin=cin, act="relu", out=out)
+torch.cuda.synchronize()
+lib = _native.load(); n = 8192 * 4; buf = (C.c_ulonglong * n)()
+lib.sd_debug_read_c32_stamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.sd_debug_read_c32_stamps(buf, n) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4).astype(np.float64)
+nk = cin // 32; tot = st.sum(1)
+print(f"cin={cin} cout={cout}: cycles per K step (64 MFMAs = 4096 cycles of one wave's matrix work; two waves share a SIMD)")
+for i, nm in enumerate(["fragment reads + MFMA", "fetch issue", "vmcnt wait + stage write", "barrier"]):
+    print(f"  {nm:26s} {np.median(st[:, i]) / nk:8.0f} cycles ({np.median(st[:, i] / tot) * 100:5.1f} %)")
+print(f"  total                      {np.median(tot) / nk:8.0f} cycles per K step")
