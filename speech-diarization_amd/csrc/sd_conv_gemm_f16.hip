@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
       }
     }
     __syncthreads();
-    sd_store_tile<TO, TBM / 2, TBN, 512>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
+    sd_store_tile<TO, TBM / 2, TBN, 512, false>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
     __syncthreads();
   }
 }
@@ -508,6 +508,7 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   const long tiles = (long)((a->M + BM - 1) / BM) * ((a->cout + BN - 1) / BN);
   SD_CHECK_ARG(tiles < (1L << 31), "sd_conv1d_cl_f16: grid too large");
   int vec = a->cout % 8 == 0 && a->ldo % 8 == 0 && a->o_col0 % 8 == 0 && sd_aligned16(a->y);
+  vec = vec && sd_aligned16(a->bias) && sd_aligned16(a->scale) && sd_aligned16(a->shift);   // null is aligned
   if (a->tee) {
     vec = vec && a->tee_lo % 8 == 0 && a->tee_hi % 8 == 0 && a->ldt % 8 == 0 && sd_aligned16(a->tee);
     if (a->tee_add) vec = vec && a->ld_ta % 8 == 0 && a->ta_col0 % 8 == 0 && sd_aligned16(a->tee_add);
@@ -525,7 +526,8 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   }();
   const bool big = a->cout >= 2048 && (long)a->taps * a->cin >= 2048;
   const int choice = forced >= 0 ? forced : (big ? 2 : 0);
-  if (xa && choice == 2) return ya ? launch_t256<_Float16>(a, vec, stream) : launch_t256<float>(a, vec, stream);
+  // (the 256x256 kernel's epilogue has no tee path)
+  if (xa && choice == 2 && !a->tee) return ya ? launch_t256<_Float16>(a, vec, stream) : launch_t256<float>(a, vec, stream);
   if (xa && ya) return launch<_Float16, _Float16>(a, vec, stream);
   if (xa && !ya) return launch<_Float16, float>(a, vec, stream);
   if (!xa && ya) return launch<float, _Float16>(a, vec, stream);

@@ -6,11 +6,18 @@
 // float4 from LDS, applies  bias -> act -> affine -> act2  in f32, converts and issues 16-byte
 // row-contiguous stores (plus the optional Res2Net tee  y + next chunk).
 //
-// The activation selector is resolved ONCE per thread, not per element: ReLU / identity (every
-// large layer of ECAPA-TDNN) take a branch-free path (max with 0 or -inf); tanh / sigmoid (the
-// attention TDNN and the SE gate) take the generic path.  An earlier version evaluated a
-// per-element `switch` inside the fully unrolled 64-element accumulator loop, which inlined
-// tanhf/expf 128 times per thread (18k instructions per kernel) and cost ~12 us per tile.
+// Two things shape the code (both measured with in-kernel cycle counters):
+// * The activation selector is resolved ONCE per thread, not per element: ReLU / identity (every
+//   large layer of ECAPA-TDNN) take a branch-free path (max with 0 or -inf).  tanh / sigmoid and
+//   the per-segment bias (the attention TDNN) are applied by a small rolled pre-pass, in place in
+//   the LDS tile.  An earlier version evaluated a per-element `switch` inside the fully unrolled
+//   accumulator loop, which inlined tanhf/expf 128 times per thread (18k instructions per kernel).
+// * The store phase contains NO loads.  On gfx950 loads and stores share `vmcnt` and may retire
+//   out of order with respect to each other, so the compiler answers any load that follows a
+//   store with `s_waitcnt vmcnt(0)`: a row loop that loaded (or might load) per row waited for
+//   the previous row's HBM write to be acknowledged, ~3.2k cycles per row, 25.6k of a 28.8k-cycle
+//   epilogue.  Everything a row needs (LDS values, the optional Res2Net `tee_add` rows) is
+//   therefore fetched for all rows first, then all stores are issued back to back.
 #pragma once
 #include "sd_common.h"
 
@@ -25,6 +32,14 @@ __device__ __forceinline__ float sd_apply_act(float v, int act) {
 
 template <typename TO> struct SdOut;
 template <> struct SdOut<float> {
+  struct raw8 { f32x4 a, b; };
+  static __device__ __forceinline__ raw8 load_raw(const float* p) {
+    return raw8{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
+  }
+  static __device__ __forceinline__ void add_raw(float* v, const raw8& r) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += r.a[e]; v[4 + e] += r.b[e]; }
+  }
   static __device__ __forceinline__ void store8(float* p, const float* v) {
     *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -37,6 +52,12 @@ template <> struct SdOut<float> {
 };
 template <> struct SdOut<_Float16> {
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  typedef h8 raw8;
+  static __device__ __forceinline__ raw8 load_raw(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
+  static __device__ __forceinline__ void add_raw(float* v, const raw8& r) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+  }
   static __device__ __forceinline__ void store8(_Float16* p, const float* v) {
     h8 r;
 #pragma unroll
@@ -50,12 +71,11 @@ template <> struct SdOut<_Float16> {
   }
 };
 
-// ROWS x COLS tile at (m0, n0); NT threads; vec != 0 when every touched row slice is 16-byte aligned
-// and cout / column offsets are multiples of 8 (decided on the host).
+// ---- fallback for outputs that cannot take 16-byte stores (cout % 8 != 0 or unaligned slices)
 template <typename TO, int ROWS, int COLS, int NT>
-__device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, const float* Cs, int ldc, int m0, int n0, int tid, int vec) {
-  constexpr int TPR = COLS / 8;     // threads per tile row
-  constexpr int RPP = NT / TPR;     // rows per pass
+__device__ __forceinline__ void sd_store_tile_scalar(const sd_conv_args& p, const float* Cs, int ldc, int m0, int n0, int tid) {
+  constexpr int TPR = COLS / 8;
+  constexpr int RPP = NT / TPR;
   TO* const Y = static_cast<TO*>(p.y);
   TO* const TEE = static_cast<TO*>(p.tee);
   const TO* const TADD = static_cast<const TO*>(p.tee_add);
@@ -63,65 +83,121 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, const float
   const int n8 = n0 + cq;
   if (n8 >= p.cout) return;
   const int nvalid = p.cout - n8 < 8 ? p.cout - n8 : 8;
-
-  float b8[8], s8[8], h8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bool ok = e < nvalid;
-    b8[e] = (ok && p.bias && !p.bias_per_seg) ? p.bias[n8 + e] : 0.f;
-    s8[e] = (ok && p.scale) ? p.scale[n8 + e] : 1.f;
-    h8[e] = (ok && p.shift) ? p.shift[n8 + e] : 0.f;
-  }
-  const bool simple = (p.act == SD_ACT_RELU || p.act == SD_ACT_NONE) && p.act2 == SD_ACT_NONE;
-  const float lo = p.act == SD_ACT_RELU ? 0.f : -INFINITY;
-  const bool tee_q = TEE && n8 >= p.tee_lo && n8 < p.tee_hi;   // exact for the vec path (ranges are multiples of 8)
-
-#pragma unroll 2
+#pragma unroll 1
   for (int rr = tid / TPR; rr < ROWS; rr += RPP) {
     const int m = m0 + rr;
     if (m >= p.M) break;
-    float v[8];
-    {
-      const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + rr * ldc + cq);
-      const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + rr * ldc + cq + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = c0[e]; v[4 + e] = c1[e]; }
-    }
-    if (p.bias_per_seg) {
-      const float* sb = p.bias + (size_t)(m / p.T) * p.cout + n8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += e < nvalid ? sb[e] : 0.f;
-    }
-    if (simple) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + b8[e], lo) * s8[e] + h8[e];
-    } else {
-#pragma unroll   // static register indices (a runtime-indexed array would live in scratch)
-      for (int e = 0; e < 8; ++e) v[e] = sd_apply_act(sd_apply_act(v[e] + b8[e], p.act) * s8[e] + h8[e], p.act2);
-    }
-    if (vec) {
-      SdOut<TO>::store8(Y + (size_t)m * p.ldo + p.o_col0 + n8, v);
-      if (tee_q) {
-        if (TADD) {
-          float t[8];
-          SdOut<TO>::load8(TADD + (size_t)m * p.ld_ta + p.ta_col0 + (n8 - p.tee_lo), t);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += t[e];
-        }
-        SdOut<TO>::store8(TEE + (size_t)m * p.ldt + (n8 - p.tee_lo), v);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (e >= nvalid) break;
-        const int n = n8 + e;
-        Y[(size_t)m * p.ldo + p.o_col0 + n] = (TO)v[e];
-        if (TEE && n >= p.tee_lo && n < p.tee_hi) {
-          float tv = v[e];
-          if (TADD) tv += (float)TADD[(size_t)m * p.ld_ta + p.ta_col0 + (n - p.tee_lo)];
-          TEE[(size_t)m * p.ldt + (n - p.tee_lo)] = (TO)tv;
-        }
+    const float* sb = p.bias ? (p.bias_per_seg ? p.bias + (size_t)(m / p.T) * p.cout : p.bias) : nullptr;
+#pragma unroll 1
+    for (int e = 0; e < nvalid; ++e) {
+      const int n = n8 + e;
+      float v = Cs[rr * ldc + cq + e] + (sb ? sb[n] : 0.f);
+      v = sd_apply_act(v, p.act) * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+      v = sd_apply_act(v, p.act2);
+      Y[(size_t)m * p.ldo + p.o_col0 + n] = (TO)v;
+      if (TEE && n >= p.tee_lo && n < p.tee_hi) {
+        if (TADD) v += (float)TADD[(size_t)m * p.ld_ta + p.ta_col0 + (n - p.tee_lo)];
+        TEE[(size_t)m * p.ldt + (n - p.tee_lo)] = (TO)v;
       }
     }
   }
+}
+
+// Store phase of the vector path for a FULL tile (no row checks: straight-line code).  TEE selects
+// the Res2Net variant, which fetches every tee_add row before its first store.
+template <typename TO, int PASSES, int RPP, bool TEE>
+__device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float* c, int ldc, size_t row0, int n8,
+                                              const float* b8, const float* s8, const float* h8, float lo) {
+  constexpr int CH = TEE ? PASSES : (PASSES < 4 ? PASSES : 4);
+  static_assert(PASSES % CH == 0, "");
+  TO* const y = static_cast<TO*>(p.y) + row0 * p.ldo + p.o_col0 + n8;
+  TO* const tee = TEE ? static_cast<TO*>(p.tee) + row0 * p.ldt + (n8 - p.tee_lo) : nullptr;
+  const TO* const ta = (TEE && p.tee_add) ? static_cast<const TO*>(p.tee_add) + row0 * p.ld_ta + p.ta_col0 + (n8 - p.tee_lo) : nullptr;
+#pragma unroll
+  for (int c0 = 0; c0 < PASSES; c0 += CH) {
+    float v[CH][8];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) SdOut<float>::load8(c + (c0 + i) * RPP * ldc, v[i]);
+    typename SdOut<TO>::raw8 t[CH];
+    if (TEE && ta) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) t[i] = SdOut<TO>::load_raw(ta + (size_t)(c0 + i) * RPP * p.ld_ta);
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = fmaxf(v[i][e] + b8[e], lo) * s8[e] + h8[e];
+      SdOut<TO>::store8(y + (size_t)(c0 + i) * RPP * p.ldo, v[i]);
+    }
+    if (TEE) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        if (ta) SdOut<TO>::add_raw(v[i], t[i]);
+        SdOut<TO>::store8(tee + (size_t)(c0 + i) * RPP * p.ldt, v[i]);
+      }
+    }
+  }
+}
+
+// ROWS x COLS tile at (m0, n0); NT threads; vec != 0 when every touched row slice and the
+// per-channel parameter vectors are 16-byte aligned and cout / column offsets are multiples of 8
+// (decided on the host).  A tile that hangs over the last row takes the element-wise fallback.
+// WITH_TEE = false (kernels the host never selects for a tee layer) drops the tee code.
+template <typename TO, int ROWS, int COLS, int NT, bool WITH_TEE = true>
+__device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, int ldc, int m0, int n0, int tid, int vec) {
+  constexpr int TPR = COLS / 8;     // threads per tile row
+  constexpr int RPP = NT / TPR;     // rows per pass
+  constexpr int PASSES = ROWS / RPP;
+  static_assert(ROWS % RPP == 0, "tile rows must be a multiple of the rows covered per pass");
+  if (!vec || m0 + ROWS > p.M) {
+    sd_store_tile_scalar<TO, ROWS, COLS, NT>(p, Cs, ldc, m0, n0, tid);
+    return;
+  }
+  const int cq = (tid % TPR) * 8;
+  const int n8 = n0 + cq;
+  const int rr0 = tid / TPR;
+  if (n8 >= p.cout) return;         // cout % 8 == 0 here: a group is entirely inside or outside
+
+  float b8[8], s8[8], h8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { b8[e] = 0.f; s8[e] = 1.f; h8[e] = 0.f; }
+  if (p.bias && !p.bias_per_seg) SdOut<float>::load8(p.bias + n8, b8);
+  if (p.scale) SdOut<float>::load8(p.scale + n8, s8);
+  if (p.shift) SdOut<float>::load8(p.shift + n8, h8);
+  const bool simple = (p.act == SD_ACT_RELU || p.act == SD_ACT_NONE) && p.act2 == SD_ACT_NONE;
+  float lo = p.act == SD_ACT_RELU ? 0.f : -INFINITY;
+  float* const c = Cs + rr0 * ldc + cq;
+
+  if (!simple || p.bias_per_seg) {
+    // rare layers: fold the per-segment bias and/or the transcendental activations into the LDS
+    // tile (every thread rewrites exactly the slots it reads back below: no barrier needed)
+#pragma unroll 1
+    for (int ps = 0; ps < PASSES; ++ps) {
+      float* cr = c + ps * RPP * ldc;
+      float v[8];
+      SdOut<float>::load8(cr, v);
+      if (p.bias_per_seg) {
+        float sb[8];
+        SdOut<float>::load8(p.bias + (size_t)((m0 + rr0 + ps * RPP) / p.T) * p.cout + n8, sb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += sb[e];
+      }
+      if (!simple) {
+#pragma unroll   // static register indices (a runtime-indexed array would live in scratch)
+        for (int e = 0; e < 8; ++e) v[e] = sd_apply_act(sd_apply_act(v[e] + b8[e], p.act) * s8[e] + h8[e], p.act2);
+      }
+      SdOut<float>::store8(cr, v);
+    }
+    if (!simple) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { b8[e] = 0.f; s8[e] = 1.f; h8[e] = 0.f; }
+      lo = -INFINITY;
+    }
+  }
+
+  const bool tee_q = WITH_TEE && p.tee && n8 >= p.tee_lo && n8 < p.tee_hi;   // ranges are multiples of 8
+  if (WITH_TEE && tee_q)
+    sd_store_rows<TO, PASSES, RPP, true>(p, c, ldc, (size_t)(m0 + rr0), n8, b8, s8, h8, lo);
+  else
+    sd_store_rows<TO, PASSES, RPP, false>(p, c, ldc, (size_t)(m0 + rr0), n8, b8, s8, h8, lo);
 }

@@ -11,12 +11,16 @@ wp = ops.pack_weight(w, dev); out = torch.empty(M, cout, device=dev)
 for _ in range(2):
     ops.conv1d_cl(x, wp, T, cin=cin, act="relu", out=out)
 torch.cuda.synchronize()
-lib = _native.load(); n = 8192 * 4; buf = (C.c_ulonglong * n)()
+lib = _native.load(); n = 8192 * 10; buf = (C.c_ulonglong * n)()
 lib.sd_debug_read_c32_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.sd_debug_read_c32_stamps(buf, n) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4).astype(np.float64)
-nk = cin // 32; tot = st.sum(1)
+st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 10).astype(np.float64)
+nk = cin // 32; tot = st[:, :4].sum(1)
 print(f"cin={cin} cout={cout}: cycles per K step (64 MFMAs = 4096 cycles of one wave's matrix work; two waves share a SIMD)")
 for i, nm in enumerate(["fragment reads + MFMA", "fetch issue", "vmcnt wait + stage write", "barrier"]):
     print(f"  {nm:26s} {np.median(st[:, i]) / nk:8.0f} cycles ({np.median(st[:, i] / tot) * 100:5.1f} %)")
 print(f"  total                      {np.median(tot) / nk:8.0f} cycles per K step")
+print(f"  prologue (launch -> K loop) {np.median(st[:, 4]):8.0f} cycles, epilogue (K loop -> stores retired) {np.median(st[:, 5]):8.0f} cycles, "
+      f"K loop {np.median(tot):8.0f} cycles: loop share of the tile {np.median(tot / (tot + st[:, 4] + st[:, 5])) * 100:5.1f} %")
+print(f"  epilogue parts: acc->LDS {np.median(st[:, 6]):6.0f}, barrier {np.median(st[:, 7]):6.0f}, params+LDS reads+math+store issue {np.median(st[:, 8]):6.0f}, "
+      f"store drain {np.median(st[:, 5] - st[:, 6] - st[:, 7] - st[:, 8]):6.0f} cycles")
