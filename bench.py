@@ -103,13 +103,20 @@ def main():
     from speech_diarization_amd import dist as sdist
     from speech_diarization_amd.engine import EmbeddingEngine
 
-    rank, local_rank, world = sdist.init_from_env("nccl")
+    # RCCL ("nccl") is the product path.  SD_BENCH_BACKEND=gloo exists only to rehearse the N>1
+    # control flow on a one-GPU box (ranks then share the card; RCCL refuses two ranks per device).
+    backend = os.environ.get("SD_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"LOCAL_RANK={local_rank} but only {n_dev} GPU(s) visible")
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
+    rank, local_rank, world = sdist.init_from_env(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     _native.load()
 
     state_dict = synth.make_ecapa_state_dict(1234)
