@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
       }
     }
     __syncthreads();
-    sd_store_tile<TO, TBM / 2, TBN, 512, false>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
+    sd_store_tile<TO, TBM / 2, TBN, 512, 1>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
     __syncthreads();
   }
 }
@@ -514,20 +514,19 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
     if (a->tee_add) vec = vec && a->ld_ta % 8 == 0 && a->ta_col0 % 8 == 0 && sd_aligned16(a->tee_add);
   }
   const bool xa = a->x_dtype == SD_DT_F16, ya = a->y_dtype == SD_DT_F16;
-  // Kernel choice, measured per shape on MI355X (tools/probe_conv.py, B*T = 205 824 rows): the 256x256
-  // LDS-DMA kernel wins on the big square MFA conv (3072x3072: 864 vs 785 TFLOP/s) and ties on
-  // 1024x1024 (584 vs 588); the register-staged 128x128 kernel with two workgroups per CU is faster
-  // on the narrow layers (Res2Net 128x384: 327, 128->3072: 205, 3072->128: 524).
-  // SD_F16_KERNEL=reg|t256 forces one kernel for A/B runs.
+  // Kernel choice, measured per shape on MI355X (tools/probe_conv.py, B*T = 1 005 000 rows): the 256x256
+  // LDS-DMA kernel wins wherever the output is wide (3072x3072: 987 vs ~800 TFLOP/s, 1024x1024: 789 vs
+  // 726, 128->3072: 342 vs 315); the register-staged 128x128 kernel with two workgroups per CU is faster
+  // on the narrow outputs (Res2Net 128x384: 555, 3072->128: 530 vs 408) and is the only one with the
+  // tee_add epilogue.  SD_F16_KERNEL=reg|t256 forces one kernel for A/B runs.
   static const int forced = [] {
     const char* e = getenv("SD_F16_KERNEL");
     if (!e) return -1;
     return e[0] == 'r' ? 0 : e[0] == 't' ? 2 : -1;
   }();
-  const bool big = a->cout >= 2048 && (long)a->taps * a->cin >= 2048;
-  const int choice = forced >= 0 ? forced : (big ? 2 : 0);
-  // (the 256x256 kernel's epilogue has no tee path)
-  if (xa && choice == 2 && !a->tee) return ya ? launch_t256<_Float16>(a, vec, stream) : launch_t256<float>(a, vec, stream);
+  const bool wide = a->cout >= 1024;
+  const int choice = forced >= 0 ? forced : (wide ? 2 : 0);
+  if (xa && choice == 2 && !(a->tee && a->tee_add)) return ya ? launch_t256<_Float16>(a, vec, stream) : launch_t256<float>(a, vec, stream);
   if (xa && ya) return launch<_Float16, _Float16>(a, vec, stream);
   if (xa && !ya) return launch<_Float16, float>(a, vec, stream);
   if (!xa && ya) return launch<float, _Float16>(a, vec, stream);

@@ -103,23 +103,24 @@ __device__ __forceinline__ void sd_store_tile_scalar(const sd_conv_args& p, cons
   }
 }
 
-// Store phase of the vector path for a FULL tile (no row checks: straight-line code).  TEE selects
-// the Res2Net variant, which fetches every tee_add row before its first store.
-template <typename TO, int PASSES, int RPP, bool TEE>
+// Store phase of the vector path for a FULL tile (no row checks: straight-line code).  TEE adds
+// the Res2Net copy of a channel range; TADD also adds another tensor's rows to that copy, which
+// are all fetched before the first store (so the rows cannot go out in small chunks).
+template <typename TO, int PASSES, int RPP, bool TEE, bool TADD>
 __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float* c, int ldc, size_t row0, int n8,
                                               const float* b8, const float* s8, const float* h8, float lo) {
-  constexpr int CH = TEE ? PASSES : (PASSES < 4 ? PASSES : 4);
-  static_assert(PASSES % CH == 0, "");
+  constexpr int CH = TADD ? PASSES : (PASSES < 4 ? PASSES : 4);
+  static_assert(PASSES % CH == 0 && (TEE || !TADD), "");
   TO* const y = static_cast<TO*>(p.y) + row0 * p.ldo + p.o_col0 + n8;
   TO* const tee = TEE ? static_cast<TO*>(p.tee) + row0 * p.ldt + (n8 - p.tee_lo) : nullptr;
-  const TO* const ta = (TEE && p.tee_add) ? static_cast<const TO*>(p.tee_add) + row0 * p.ld_ta + p.ta_col0 + (n8 - p.tee_lo) : nullptr;
+  const TO* const ta = TADD ? static_cast<const TO*>(p.tee_add) + row0 * p.ld_ta + p.ta_col0 + (n8 - p.tee_lo) : nullptr;
 #pragma unroll
   for (int c0 = 0; c0 < PASSES; c0 += CH) {
     float v[CH][8];
 #pragma unroll
     for (int i = 0; i < CH; ++i) SdOut<float>::load8(c + (c0 + i) * RPP * ldc, v[i]);
     typename SdOut<TO>::raw8 t[CH];
-    if (TEE && ta) {
+    if (TADD) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) t[i] = SdOut<TO>::load_raw(ta + (size_t)(c0 + i) * RPP * p.ld_ta);
     }
@@ -132,7 +133,7 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
     if (TEE) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        if (ta) SdOut<TO>::add_raw(v[i], t[i]);
+        if (TADD) SdOut<TO>::add_raw(v[i], t[i]);
         SdOut<TO>::store8(tee + (size_t)(c0 + i) * RPP * p.ldt, v[i]);
       }
     }
@@ -142,8 +143,9 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
 // ROWS x COLS tile at (m0, n0); NT threads; vec != 0 when every touched row slice and the
 // per-channel parameter vectors are 16-byte aligned and cout / column offsets are multiples of 8
 // (decided on the host).  A tile that hangs over the last row takes the element-wise fallback.
-// WITH_TEE = false (kernels the host never selects for a tee layer) drops the tee code.
-template <typename TO, int ROWS, int COLS, int NT, bool WITH_TEE = true>
+// TEE_MODE: 2 = full (tee with or without tee_add), 1 = tee without tee_add only (the host never
+// selects such a kernel for a tee_add layer; saves the registers of the prefetched rows).
+template <typename TO, int ROWS, int COLS, int NT, int TEE_MODE = 2>
 __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, int ldc, int m0, int n0, int tid, int vec) {
   constexpr int TPR = COLS / 8;     // threads per tile row
   constexpr int RPP = NT / TPR;     // rows per pass
@@ -195,9 +197,12 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
     }
   }
 
-  const bool tee_q = WITH_TEE && p.tee && n8 >= p.tee_lo && n8 < p.tee_hi;   // ranges are multiples of 8
-  if (WITH_TEE && tee_q)
-    sd_store_rows<TO, PASSES, RPP, true>(p, c, ldc, (size_t)(m0 + rr0), n8, b8, s8, h8, lo);
-  else
-    sd_store_rows<TO, PASSES, RPP, false>(p, c, ldc, (size_t)(m0 + rr0), n8, b8, s8, h8, lo);
+  const bool tee_q = p.tee && n8 >= p.tee_lo && n8 < p.tee_hi;   // ranges are multiples of 8
+  const size_t row0 = (size_t)(m0 + rr0);
+  if (tee_q) {
+    if (TEE_MODE == 2 && p.tee_add) sd_store_rows<TO, PASSES, RPP, true, (TEE_MODE == 2)>(p, c, ldc, row0, n8, b8, s8, h8, lo);
+    else sd_store_rows<TO, PASSES, RPP, true, false>(p, c, ldc, row0, n8, b8, s8, h8, lo);
+  } else {
+    sd_store_rows<TO, PASSES, RPP, false, false>(p, c, ldc, row0, n8, b8, s8, h8, lo);
+  }
 }
