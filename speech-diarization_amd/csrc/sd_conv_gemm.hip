@@ -17,6 +17,8 @@
 // Each lane reads FOUR consecutive k (one ds_read_b128) at k0 + 4h and feeds
 // element r to MFMA r, so MFMA r sums k in {k0 + r, k0 + 4 + r}; A and B use the
 // same permutation, and the sum over k is order independent up to rounding.
+#include <cstdlib>
+
 #include "sd_common.h"
 #include "sd_epilogue.h"
 
@@ -33,7 +35,7 @@ static_assert(BM * LDC <= 2 * (BM + BN) * LDP, "C tile must fit in the operand s
 __device__ unsigned long long sd_c32_stamp_buf[8192 * 10];
 #endif
 
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p, const int vec) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p, const int vec, const int order) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef SD_STAMP
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -46,21 +48,30 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   const int wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
 
-  // Workgroups are dealt round-robin over the eight XCDs (one L2 each).  When the whole weight
-  // matrix fits in an L2 (<= 4 MB: every layer but the 3C->3C conv), a bijective remap sends
-  // consecutive tiles (n fastest: they share the A row panel) to ONE XCD, so A is fetched once
-  // instead of eight times.  For the 36 MB 3C->3C weights the natural order is kept: with
-  // n_tiles a multiple of 8 each XCD then always sees the same 1/8 of the weight columns and
-  // keeps them resident, which measured better (131 vs 124 TFLOP/s) than sharing the A panel.
+  // Workgroups are dealt round-robin over the eight XCDs (one 4 MB L2 each).  A bijective remap
+  // first gives every XCD a contiguous range of logical workgroups; those are then laid out in
+  // bands of 8 row tiles, n-major inside a band, so the ~64 workgroups an XCD runs at a time form
+  // an 8 x 8 patch of tiles: each A row panel and each weight column panel it touches is shared
+  // by 8 workgroups.  Measured: L2 fill traffic of the C->C layers 13.6 -> 8.8 GB per launch
+  // (A alone is 1.7 GB; workgroups drift apart in K, so whole panels would have to stay resident
+  // for more), throughput unchanged within the box-to-box noise (the kernel is MFMA bound).
+  // SD_TILE_ORDER=0 (host, diagnostic) keeps the launch order.
   const int n_tiles = (p.cout + BN - 1) / BN;
-  int wg = blockIdx.x;
-  if ((size_t)p.cout * p.taps * p.cin_pad <= (size_t)1 << 20) {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  int tile_m, tile_n;
+  if (order == 0) {
+    tile_n = blockIdx.x % n_tiles;
+    tile_m = blockIdx.x / n_tiles;
+  } else {
+    const int nwg = gridDim.x, bx = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bx & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
+    const int m_tiles = nwg / n_tiles;
+    const int band = wg / (8 * n_tiles);
+    const int in_band = wg - band * 8 * n_tiles;
+    const int rows = m_tiles - band * 8 < 8 ? m_tiles - band * 8 : 8;
+    tile_n = in_band / rows;
+    tile_m = band * 8 + in_band % rows;
   }
-  const int tile_n = wg % n_tiles;
-  const int tile_m = wg / n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // staging role: 8 threads per 32-float row, 4 rows per thread.  Rows past M and output
@@ -364,11 +375,15 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  static const int order = [] {
+    const char* e = getenv("SD_TILE_ORDER");
+    return e ? atoi(e) : 1;
+  }();
   {
     SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream),
                      2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
     hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds,
-                       static_cast<hipStream_t>(stream), *a, vec);
+                       static_cast<hipStream_t>(stream), *a, vec, order);
   }
   SD_CHECK_LAUNCH("conv_gemm_f32_kernel");
   return SD_OK;
