@@ -89,12 +89,16 @@ def cpu_baseline(state_dict, wav_dev, budget_s):
             "sample": f"{done} of the same synthetic 2 s segments, batch {batch}, torch-CPU f32 oracle, {dt:.1f} s"}
 
 
-def load_traffic():
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f)
     return {}
+
+
+def load_traffic():
+    return load_profile_json("traffic.json")
 
 
 def main():
@@ -215,6 +219,8 @@ def main():
                 "achieved": conv_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
                 "frac": conv_tflops / mfma_peak,
                 "traffic": traffic.get(conv_kernel),
+                # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass of this command (profiles/mfma_util.json), not live
+                "mfma_util_pmc": (load_profile_json("mfma_util.json").get(conv_kernel) or {}).get("mfma_util"),
                 "launches": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
                 "flops_per_launch": conv_flops / max(conv_n, 1),
                 "share_of_step_time": conv_ms * 1e-3 / dt,
