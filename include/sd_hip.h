@@ -158,6 +158,15 @@ int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate, const voi
                             void* y, int ldy, int y_col0, int B, int T, int C, int dtype, sd_stream_t stream);
 int sd_asp_pool_dt(const void* logit, int ldl, const void* h, int dtype, int ldh,
                    int B, int T, int C, float eps, float* out, sd_stream_t stream);
+/* attention-logit conv + attentive statistics pooling in one kernel: logits = a1 * wc^T (the conv's bias
+ * cannot change a softmax over T and is not an argument), a = softmax_T(logits), out [B][2*C] = [mu | sd].
+ * a1 [B*T][att] contiguous, wc packed [C][1][att], h [B*T][ldh], all in `dtype`.  Replaces, for
+ * speechbrain's AttentiveStatisticsPooling, `asp.conv` + the pooling that sd_asp_pool_dt does on stored
+ * logits.  sd_asp_attend_pool_supported() says whether the geometry is covered (f16, att = 128,
+ * C % 256 == 0, T <= 256); the _dt entry returns SD_ERR_UNSUPPORTED (nothing launched) otherwise. */
+int sd_asp_attend_pool_supported(int dtype, int T, int C, int att);
+int sd_asp_attend_pool_dt(const void* a1, const void* wc, const void* h, int dtype, int ldh,
+                          int B, int T, int C, int att, float eps, float* out, sd_stream_t stream);
 
 /* ------------------------------------------------------------ ECAPA-TDNN */
 

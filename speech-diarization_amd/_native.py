@@ -106,6 +106,8 @@ PROTOTYPES = {
     "sd_seg_mean_std_dt": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "sd_se_scale_residual_dt": (_I, [_P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sd_asp_pool_dt": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "sd_asp_attend_pool_supported": (_I, [_I, _I, _I, _I]),
+    "sd_asp_attend_pool_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "sd_ecapa_forward_f16": (_I, [C.POINTER(sd_ecapa_weights), _P, _I, _I, _P, _P, _Z, _P]),
     "sd_seg_mean_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sd_seg_mean_std_f32": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),

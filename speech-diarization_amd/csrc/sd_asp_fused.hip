@@ -1,0 +1,215 @@
+// Attention logits + attentive statistics pooling in one kernel (f16 activations).
+//
+// speechbrain's AttentiveStatisticsPooling ends with  Conv1d(att -> C, k=1)  -> softmax over time
+// -> weighted mean / std of h (reached from [REF speech_encode.py:77]).
+// Run as separate operators that costs a [B*T][C] logits tensor written and read back (12 GB per
+// 5000 segments at C = 3072) around a K = 128 GEMM whose tiles are all epilogue.
+//
+// Here a workgroup owns (segment, 256 channels) and splits TIME over its 4 waves, flash-attention
+// style.  Each wave keeps the MFMA B fragments of its <= 64 frames of the attention activations
+// a1 [T][128] in registers for the whole kernel (loaded once, straight from global memory), and
+// walks the 256 channels in groups of 16: logits tile = W[16 ch][128] x a1^T on
+// v_mfma_f32_16x16x32_f16 with CHANNELS as MFMA rows and TIME as MFMA columns, so a lane holds 4
+// consecutive channels of one frame per tile -- exactly one 8-byte load of h.  Logits never leave
+// the accumulators.  Per channel the wave reduces (max, sum w, sum w h, sum w h^2) over its frames
+// with 16-lane DPP reductions; the four waves' partial results are merged through LDS with the
+// usual running-max rescaling, and only [mu | sd] (2 C floats per segment) is written.
+//
+// The conv's bias is not needed: softmax over time is invariant to a per-channel shift.
+// var = E_w[h^2] - mu^2 in f32 (h has f16 precision here, 11 bits; the f32 cancellation error is
+// 2^-24 relative to E[h^2]).
+#include "sd_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int AK = 128;       // attention channels = K of the logits GEMM
+constexpr int WLD = AK + 8;   // LDS row stride of the weight tile in halves (272 B: conflict-free ds_read_b128)
+constexpr int CPB = 256;      // channels per workgroup
+constexpr int NG = CPB / 16;  // channel groups of 16 (one MFMA row tile)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+
+// reduction over the 16 lanes of a DPP row; every lane of the row ends up with the result
+template <bool MAX>
+__device__ __forceinline__ float red16(float v) {
+#define SD_RED_OP(a, b) (MAX ? fmaxf((a), (b)) : (a) + (b))
+  v = SD_RED_OP(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = SD_RED_OP(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = SD_RED_OP(v, dpp_mov<0x141>(v));   // row_half_mirror
+  v = SD_RED_OP(v, dpp_mov<0x140>(v));   // row_mirror
+#undef SD_RED_OP
+  return v;
+}
+
+template <int TPW>   // 16-frame tiles per wave: T <= 64 * TPW
+__global__ __launch_bounds__(256, 2) void asp_attend_pool_f16_kernel(const _Float16* __restrict__ a1, const _Float16* __restrict__ wc,
+                                                                     const _Float16* __restrict__ h, int ldh, int Tn, int C,
+                                                                     float eps, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 sw[];   // [CPB][WLD] weights; reused for the partial statistics
+  const int cblocks = C / CPB;
+  const int b = blockIdx.x / cblocks, cblk = blockIdx.x % cblocks;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 15, quad = lane >> 4;      // MFMA column (frame) / k group and output row group
+
+  // this wave's frames: B fragments for the whole kernel.  lane (col, quad) holds a1[t0 + 16 j + col][32 ks + 8 quad .. +7]
+  const int t0 = wid * TPW * 16;
+  h8 af[TPW][AK / 32];
+  {
+    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int t = t0 + j * 16 + col;
+      const _Float16* ar = a1 + ((size_t)b * Tn + (t < Tn ? t : 0)) * AK + quad * 8;
+#pragma unroll
+      for (int ks = 0; ks < AK / 32; ++ks) af[j][ks] = t < Tn ? *reinterpret_cast<const h8*>(ar + ks * 32) : z;
+    }
+  }
+  // weight tile -> LDS
+  {
+    const _Float16* wb = wc + (size_t)cblk * CPB * AK;
+#pragma unroll 4
+    for (int p = tid; p < CPB * (AK / 8); p += 256) {
+      const int row = p / (AK / 8), q = (p % (AK / 8)) * 8;
+      *reinterpret_cast<h8*>(sw + row * WLD + q) = *reinterpret_cast<const h8*>(wb + (size_t)row * AK + q);
+    }
+  }
+  __syncthreads();
+
+  // h pointer of this lane: frame t0 + col (+16 j), channels cblk*256 + 16 g + 4 quad .. +3
+  const _Float16* hl = h + ((size_t)b * Tn + t0 + col) * ldh + (size_t)cblk * CPB + 4 * quad;
+  bool live[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) live[j] = t0 + j * 16 + col < Tn;
+  const h4 hz = {0, 0, 0, 0};
+  auto load_h = [&](int g, h4* dst) {
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) dst[j] = live[j] ? *reinterpret_cast<const h4*>(hl + (size_t)j * 16 * ldh + g * 16) : hz;
+  };
+
+  // per-wave partial statistics of channel 16 g + 4 quad + r: (max, sum w, sum w h, sum w h^2), kept by lane col == g % 16
+  float pm[4], pd[4], pn[4], pq[4];
+  h4 hv[TPW], hn[TPW];
+  load_h(0, hv);
+#pragma unroll 1
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) load_h(g + 1, hn);
+    // A fragment: lane (col, quad) holds W[16 g + col][32 ks + 8 quad .. +7]
+    const _Float16* wr = sw + (g * 16 + col) * WLD + quad * 8;
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < AK / 32; ++ks) {
+      const h8 wf = *reinterpret_cast<const h8*>(wr + ks * 32);
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af[j][ks], acc[j], 0, 0, 0);
+    }
+    float m[4], d[4], n[4], q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        acc[j][r] = live[j] ? acc[j][r] : -INFINITY;
+        mx = fmaxf(mx, acc[j][r]);
+      }
+      mx = red16<true>(mx);
+      const float base = mx == -INFINITY ? 0.f : mx;     // a wave whose frames are all past T: every w = exp(-inf) = 0
+      float dd = 0.f, nn = 0.f, qq = 0.f;
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const float w = __expf(acc[j][r] - base);
+        const float hh = (float)hv[j][r];
+        const float wh = w * hh;
+        dd += w;
+        nn += wh;
+        qq += wh * hh;
+      }
+      m[r] = mx; d[r] = red16<false>(dd); n[r] = red16<false>(nn); q[r] = red16<false>(qq);
+    }
+    if (col == (g & 15)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pm[r] = m[r]; pd[r] = d[r]; pn[r] = n[r]; pq[r] = q[r]; }
+    }
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) hv[j] = hn[j];
+  }
+
+  // merge the four waves: stats[wave][channel][4] in LDS (the weight tile is dead)
+  __syncthreads();
+  float* st = reinterpret_cast<float*>(sw);
+  {
+    // lane (col, quad) kept group g = col: channels 16 col + 4 quad + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f32x4*>(st + ((size_t)wid * CPB + 16 * col + 4 * quad + r) * 4) = f32x4{pm[r], pd[r], pn[r], pq[r]};
+  }
+  __syncthreads();
+  {
+    const int c = tid;   // 256 threads = 256 channels
+    f32x4 s[4];
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      s[w] = *reinterpret_cast<const f32x4*>(st + ((size_t)w * CPB + c) * 4);
+      M = fmaxf(M, s[w][0]);
+    }
+    float den = 0.f, num = 0.f, sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float sc = s[w][0] == -INFINITY ? 0.f : __expf(s[w][0] - M);
+      den += sc * s[w][1];
+      num += sc * s[w][2];
+      sq += sc * s[w][3];
+    }
+    const float mu = num / den;
+    const float var = sq / den - mu * mu;
+    float* o = out + (size_t)b * 2 * C + (size_t)cblk * CPB + c;
+    o[0] = mu;
+    o[C] = sqrtf(fmaxf(var, eps));
+  }
+}
+
+template <int TPW>
+int launch_f16(const void* a1, const void* wc, const void* h, int ldh, int B, int T, int C, float eps, float* out, hipStream_t s) {
+  auto kern = asp_attend_pool_f16_kernel<TPW>;
+  const size_t lds = (size_t)CPB * WLD * sizeof(_Float16);
+  static_assert((size_t)CPB * WLD * sizeof(_Float16) >= (size_t)4 * CPB * 4 * sizeof(float), "statistics must fit in the weight tile");
+  static bool attr_set = false;
+  if (!attr_set) {
+    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * (C / CPB))), dim3(256), lds, s, static_cast<const _Float16*>(a1),
+                     static_cast<const _Float16*>(wc), static_cast<const _Float16*>(h), ldh, T, C, eps, out);
+  SD_CHECK_LAUNCH("asp_attend_pool_f16_kernel");
+  return SD_OK;
+}
+
+}  // namespace
+
+extern "C" int sd_asp_attend_pool_supported(int dtype, int T, int C, int att) {
+  return dtype == SD_DT_F16 && att == AK && C > 0 && C % CPB == 0 && T > 0 && T <= 256;
+}
+
+extern "C" int sd_asp_attend_pool_dt(const void* a1, const void* wc, const void* h, int dtype, int ldh, int B, int T, int C,
+                                     int att, float eps, float* out, sd_stream_t stream) {
+  SD_CHECK_ARG(a1 && wc && h && out, "sd_asp_attend_pool_dt: null pointer");
+  SD_CHECK_ARG(B >= 0 && (long)B * (C > 0 ? C : 1) < (1L << 31), "sd_asp_attend_pool_dt: B=%d", B);
+  if (!sd_asp_attend_pool_supported(dtype, T, C, att))
+    return sd_set_error(SD_ERR_UNSUPPORTED, "sd_asp_attend_pool_dt: dtype=%d T=%d C=%d att=%d not covered (f16, att=128, C%%256==0, T<=256)",
+                        dtype, T, C, att);
+  SD_CHECK_ARG(ldh >= C && ldh % 4 == 0, "sd_asp_attend_pool_dt: ldh=%d (need >= C and a multiple of 4)", ldh);
+  SD_CHECK_ARG(sd_aligned16(a1) && sd_aligned16(wc) && sd_aligned16(h) && sd_aligned16(out), "sd_asp_attend_pool_dt: pointers must be 16-byte aligned");
+  if (B == 0) return SD_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (T <= 64) return launch_f16<1>(a1, wc, h, ldh, B, T, C, eps, out, s);
+  if (T <= 128) return launch_f16<2>(a1, wc, h, ldh, B, T, C, eps, out, s);
+  return launch_f16<4>(a1, wc, h, ldh, B, T, C, eps, out, s);
+}

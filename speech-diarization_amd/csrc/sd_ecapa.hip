@@ -201,10 +201,18 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     sd_conv_args a = conv_of(w->asp_tdnn_h, b.h, dt, Cm, 0, b.a1, dt, w->att_channels, 0, M, T, SD_ACT_RELU);
     a.bias = b.gbias; a.bias_per_seg = 1; a.act2 = SD_ACT_TANH;
     SD_TRY(run_conv(a, stream));
-    sd_conv_args c = conv_of(w->asp_conv, b.a1, dt, w->att_channels, 0, b.e, dt, Cm, 0, M, T, SD_ACT_NONE);
-    SD_TRY(run_conv(c, stream));
+    // asp.conv + softmax over T + weighted statistics: one kernel where the geometry allows (the
+    // [M][3C] logits are then never stored), else the conv followed by the pooling kernel
+    const bool fused = w->asp_conv.taps == 1 && w->asp_conv.cin_pad == w->att_channels &&
+                       sd_asp_attend_pool_supported(dt, T, Cm, w->att_channels);
+    if (fused) {
+      SD_TRY(sd_asp_attend_pool_dt(b.a1, w->asp_conv.w, b.h, dt, Cm, B, T, Cm, w->att_channels, w->asp_eps, b.pooled, stream));
+    } else {
+      sd_conv_args c = conv_of(w->asp_conv, b.a1, dt, w->att_channels, 0, b.e, dt, Cm, 0, M, T, SD_ACT_NONE);
+      SD_TRY(run_conv(c, stream));
+      SD_TRY(sd_asp_pool_dt(b.e, Cm, b.h, dt, Cm, B, T, Cm, w->asp_eps, b.pooled, stream));
+    }
   }
-  SD_TRY(sd_asp_pool_dt(b.e, Cm, b.h, dt, Cm, B, T, Cm, w->asp_eps, b.pooled, stream));
   // asp_bn (folded into the weights by the host) + fc
   {
     sd_conv_args a = conv_of(w->fc, b.pooled, F32, 2 * Cm, 0, emb, F32, w->emb_dim, 0, B, 1, SD_ACT_NONE);

@@ -123,6 +123,28 @@ def asp_pool(logit: torch.Tensor, h: torch.Tensor, B: int, T: int, eps: float = 
     return out
 
 
+def asp_attend_pool(a1: torch.Tensor, wc_packed: torch.Tensor, h: torch.Tensor, B: int, T: int, eps: float = 1e-12) -> torch.Tensor:
+    """softmax_T(a1 @ wc^T) weighted mean / std of h in one kernel (`asp.conv` + pooling of speechbrain's
+    AttentiveStatisticsPooling): a1 [B*T, att], wc_packed from `pack_weight`, h [B*T, C] -> f32 [B, 2C].
+    Raises for geometries the fused kernel does not cover (see `asp_attend_pool_supported`)."""
+    _need_cuda(a1, h, wc_packed)
+    lib = N.load()
+    C_, att = h.shape[1], a1.shape[1]
+    if a1.dtype != h.dtype or wc_packed.dtype != h.dtype:
+        raise ValueError("a1, wc and h must share a dtype")
+    dt = N.SD_DT_F16 if h.dtype == torch.float16 else N.SD_DT_F32
+    a1 = a1.contiguous()
+    out = torch.empty((B, 2 * C_), dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        N.check(lib.sd_asp_attend_pool_dt(a1.data_ptr(), wc_packed.data_ptr(), h.data_ptr(), dt, h.stride(0), B, T, C_, att,
+                                          C.c_float(eps), out.data_ptr(), _stream(h)), "sd_asp_attend_pool_dt")
+    return out
+
+
+def asp_attend_pool_supported(dtype: torch.dtype, T: int, C_: int, att: int) -> bool:
+    return bool(N.load().sd_asp_attend_pool_supported(N.SD_DT_F16 if dtype == torch.float16 else N.SD_DT_F32, T, C_, att))
+
+
 def l2norm_rows(x: torch.Tensor, eps_add: float = 0.0, sklearn_zero_guard: bool = False) -> torch.Tensor:
     _need_cuda(x)
     x = x.contiguous().float()
