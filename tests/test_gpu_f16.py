@@ -175,12 +175,13 @@ def test_ecapa_f16_small_geometry(dev, width, B, n):
     assert cd.max() < 1e-4, cd                # north_star bar: 1e-3
 
 
-def test_ecapa_f16_full_geometry(dev):
+@pytest.mark.parametrize("B,n", [(4, 32000), (2, 16000), (2, 8000), (1, 48000)])   # T = 201 / 101 / 51: fused attention pooling; 301: two-operator path
+def test_ecapa_f16_full_geometry(dev, B, n):
     from oracle import pipeline_ref
     from speech_diarization_amd import synth
     from speech_diarization_amd.engine import EmbeddingEngine
     sd = synth.make_ecapa_state_dict(1234)
-    wav = synth.synthetic_segments(0, 4, 32000)
+    wav = synth.synthetic_segments(0, B, n)
     got = EmbeddingEngine(sd, dev, precision="f16").embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
     ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
     cd = _cos_dist(got, ref)
