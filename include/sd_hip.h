@@ -162,7 +162,7 @@ int sd_asp_pool_dt(const void* logit, int ldl, const void* h, int dtype, int ldh
  * cannot change a softmax over T and is not an argument), a = softmax_T(logits), out [B][2*C] = [mu | sd].
  * a1 [B*T][att] contiguous, wc packed [C][1][att], h [B*T][ldh], all in `dtype`.  Replaces, for
  * speechbrain's AttentiveStatisticsPooling, `asp.conv` + the pooling that sd_asp_pool_dt does on stored
- * logits.  sd_asp_attend_pool_supported() says whether the geometry is covered (f16, att = 128,
+ * logits.  sd_asp_attend_pool_supported() says whether the geometry is covered (att = 128,
  * C % 256 == 0, T <= 256); the _dt entry returns SD_ERR_UNSUPPORTED (nothing launched) otherwise. */
 int sd_asp_attend_pool_supported(int dtype, int T, int C, int att);
 int sd_asp_attend_pool_dt(const void* a1, const void* wc, const void* h, int dtype, int ldh,

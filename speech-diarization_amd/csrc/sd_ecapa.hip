@@ -16,6 +16,8 @@
 //   * the Res2Net add  c_{j+1} + y_j  is produced by the epilogue of conv j ("tee");
 //   * the attention TDNN's global-context columns (mean/std broadcast over T) collapse
 //     to a per-segment bias computed by one tiny GEMM.
+#include <cstdlib>
+
 #include "sd_common.h"
 
 namespace {
@@ -203,7 +205,11 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     SD_TRY(run_conv(a, stream));
     // asp.conv + softmax over T + weighted statistics: one kernel where the geometry allows (the
     // [M][3C] logits are then never stored), else the conv followed by the pooling kernel
-    const bool fused = w->asp_conv.taps == 1 && w->asp_conv.cin_pad == w->att_channels &&
+    static const bool fuse_ok = [] {     // SD_ASP_FUSED=0: A/B switch for measurements
+      const char* e = getenv("SD_ASP_FUSED");
+      return !(e && e[0] == '0');
+    }();
+    const bool fused = fuse_ok && w->asp_conv.taps == 1 && w->asp_conv.cin_pad == w->att_channels &&
                        sd_asp_attend_pool_supported(dt, T, Cm, w->att_channels);
     if (fused) {
       SD_TRY(sd_asp_attend_pool_dt(b.a1, w->asp_conv.w, b.h, dt, Cm, B, T, Cm, w->att_channels, w->asp_eps, b.pooled, stream));
