@@ -20,7 +20,7 @@ SD_ACT_NONE, SD_ACT_RELU, SD_ACT_TANH, SD_ACT_SIGMOID = 0, 1, 2, 3
 SD_DT_F32, SD_DT_F16 = 0, 1
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
-SD_ABI_VERSION = 2
+SD_ABI_VERSION = 3
 SD_PROF_CONV_GEMM, SD_PROF_FBANK = 0, 1
 
 
@@ -53,6 +53,7 @@ class sd_conv_args(C.Structure):
         ("tee", C.c_void_p), ("ldt", C.c_int), ("tee_lo", C.c_int), ("tee_hi", C.c_int),
         ("tee_add", C.c_void_p), ("ld_ta", C.c_int), ("ta_col0", C.c_int),
         ("x_dtype", C.c_int), ("y_dtype", C.c_int),
+        ("colstat", C.c_void_p),
     ]
 
 
@@ -103,6 +104,8 @@ PROTOTYPES = {
     "sd_fbank_f32": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_conv1d_cl_f32": (_I, [C.POINTER(sd_conv_args), _P]),
     "sd_conv1d_cl_f16": (_I, [C.POINTER(sd_conv_args), _P]),
+    "sd_colstat_floats": (_Z, [_I, _I]),
+    "sd_colstat_finish_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "sd_seg_mean_std_dt": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "sd_se_scale_residual_dt": (_I, [_P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sd_asp_pool_dt": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P]),

@@ -357,11 +357,17 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
     vec = vec && a->tee_lo % 8 == 0 && a->tee_hi % 8 == 0 && a->ldt % 4 == 0 && sd_aligned16(a->tee);
     if (a->tee_add) vec = vec && a->ld_ta % 4 == 0 && a->ta_col0 % 4 == 0 && sd_aligned16(a->tee_add);
   }
+  if (a->colstat) {
+    const bool simple = (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg;
+    if (!(vec && simple && a->T >= 128 && a->cout % 256 == 0 && !a->tee))
+      return sd_set_error(SD_ERR_UNSUPPORTED, "sd_conv1d_cl_f32: colstat needs T >= 128, cout %% 256 == 0, relu/identity, per-channel bias, "
+                          "aligned slices and no tee (T=%d cout=%d act=%d/%d)", a->T, a->cout, a->act, a->act2);
+  }
   const long tiles_m = (a->M + BM - 1) / BM;
   const long tiles_n = (a->cout + BN - 1) / BN;
   SD_CHECK_ARG(tiles_m * tiles_n < (1L << 31), "sd_conv1d_cl_f32: grid too large");
   // too few 128x128 tiles to fill the chip (per-segment layers): 32x32 tiles with in-workgroup split-K
-  if (a->T == 1 && a->taps == 1 && !a->tee && tiles_m * tiles_n < 128) {
+  if (a->T == 1 && a->taps == 1 && !a->tee && !a->colstat && tiles_m * tiles_n < 128) {
     const long g = (long)((a->M + SK_T - 1) / SK_T) * ((a->cout + SK_T - 1) / SK_T);
     // (not counted in the SD_PROF_CONV_GEMM roofline figures: a different kernel, 0.2 % of the flops)
     hipLaunchKernelGGL(skinny_gemm_f32_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), *a);

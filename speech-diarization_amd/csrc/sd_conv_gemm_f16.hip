@@ -513,6 +513,12 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
     vec = vec && a->tee_lo % 8 == 0 && a->tee_hi % 8 == 0 && a->ldt % 8 == 0 && sd_aligned16(a->tee);
     if (a->tee_add) vec = vec && a->ld_ta % 8 == 0 && a->ta_col0 % 8 == 0 && sd_aligned16(a->tee_add);
   }
+  if (a->colstat) {
+    const bool simple = (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg;
+    if (!(vec && simple && a->T >= 128 && a->cout % 256 == 0 && !a->tee))
+      return sd_set_error(SD_ERR_UNSUPPORTED, "sd_conv1d_cl_f16: colstat needs T >= 128, cout %% 256 == 0, relu/identity, per-channel bias, "
+                          "aligned slices and no tee (T=%d cout=%d act=%d/%d)", a->T, a->cout, a->act, a->act2);
+  }
   const bool xa = a->x_dtype == SD_DT_F16, ya = a->y_dtype == SD_DT_F16;
   // Kernel choice, measured per shape on MI355X (tools/probe_conv.py, B*T = 1 005 000 rows): the 256x256
   // LDS-DMA kernel wins wherever the output is wide (3072x3072: 987 vs ~800 TFLOP/s, 1024x1024: 789 vs

@@ -144,9 +144,11 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   const int C = w->channels, Cm = w->mfa_channels, chunk = C / w->res2_scale;
   const int F32 = SD_DT_F32;
   const size_t es = dt == SD_DT_F16 ? 2 : 4;
-  auto col = [&](void* p, size_t c) { return static_cast<void*>(static_cast<char*>(p) + c * es); };
-  (void)col;
 
+  static const bool colstat_ok = [] {     // SD_COLSTAT=0: A/B switch for measurements
+    const char* e = getenv("SD_COLSTAT");
+    return !(e && e[0] == '0');
+  }();
   // block 0: TDNNBlock(n_mels -> C, k=5) on the f32 features
   {
     sd_conv_args a = conv_of(w->block0, feats, F32, w->n_mels, 0, b.x0, dt, C, 0, M, T, SD_ACT_RELU);
@@ -172,13 +174,18 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       }
       SD_TRY(run_conv(a, stream));
     }
-    // tdnn2
+    // tdnn2; the SE squeeze (mean over T) comes out of its epilogue as per-tile column sums where the
+    // geometry allows (the Res2Net scratch s0 is dead and holds them), else from a pass over t2
     {
       sd_conv_args a = conv_of(blk.tdnn2, b.r, dt, C, 0, b.t2, dt, C, 0, M, T, SD_ACT_RELU);
+      const bool stat = colstat_ok && T >= 128 && C % 256 == 0 &&
+                        sd_colstat_floats(M, C) * sizeof(float) <= (size_t)M * chunk * es;
+      if (stat) a.colstat = static_cast<float*>(b.s0);
       SD_TRY(run_conv(a, stream));
+      if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
+      else SD_TRY(sd_seg_mean_std_dt(b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
     }
     // squeeze-excitation gate (per-segment, f32)
-    SD_TRY(sd_seg_mean_std_dt(b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
     {
       sd_conv_args a = conv_of(blk.se1, b.semean, F32, C, 0, b.seh, F32, blk.se1.cout, 0, B, 1, SD_ACT_RELU);
       SD_TRY(run_conv(a, stream));
@@ -189,13 +196,18 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     SD_TRY(sd_se_scale_residual_dt(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, dt, stream));
     xin = b.xcat; ldin = Cm; colin = i * C;
   }
-  // multi-layer feature aggregation
+  // multi-layer feature aggregation; the global mean / std of attentive pooling likewise from the
+  // epilogue (column sums in r, dead since the last block's tdnn2)
   {
     sd_conv_args a = conv_of(w->mfa, b.xcat, dt, Cm, 0, b.h, dt, Cm, 0, M, T, SD_ACT_RELU);
+    const bool stat = colstat_ok && T >= 128 && Cm % 256 == 0 &&
+                      sd_colstat_floats(M, Cm) * sizeof(float) <= (size_t)M * C * es;
+    if (stat) a.colstat = static_cast<float*>(b.r);
     SD_TRY(run_conv(a, stream));
+    if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
+    else SD_TRY(sd_seg_mean_std_dt(b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
   }
   // attentive statistics pooling with global context
-  SD_TRY(sd_seg_mean_std_dt(b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
   {
     sd_conv_args g = conv_of(w->asp_tdnn_g, b.stats, F32, 2 * Cm, 0, b.gbias, F32, w->att_channels, 0, B, 1, SD_ACT_NONE);
     g.scale = nullptr; g.shift = nullptr;

@@ -106,10 +106,13 @@ __device__ __forceinline__ void sd_store_tile_scalar(const sd_conv_args& p, cons
 // Store phase of the vector path for a FULL tile (no row checks: straight-line code).  TEE adds
 // the Res2Net copy of a channel range; TADD also adds another tensor's rows to that copy, which
 // are all fetched before the first store (so the rows cannot go out in small chunks).
-template <typename TO, int PASSES, int RPP, bool TEE, bool TADD>
+template <typename TO, int PASSES, int RPP, bool TEE, bool TADD, bool STAT>
 __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float* c, int ldc, size_t row0, int n8,
-                                              const float* b8, const float* s8, const float* h8, float lo) {
-  constexpr int CH = TADD ? PASSES : (PASSES < 4 ? PASSES : 4);
+                                              const float* b8, const float* s8, const float* h8, float lo,
+                                              int rr0, int rb, float (*st)[8]) {
+  // rows per fetch/store chunk: all of them when tee_add rows must be prefetched; 1 with the 32 statistics
+  // accumulators live (the 256x256 kernel has 128 VGPRs beside its accumulators); else 4
+  constexpr int CH = TADD ? PASSES : (STAT ? 1 : (PASSES < 4 ? PASSES : 4));
   static_assert(PASSES % CH == 0 && (TEE || !TADD), "");
   TO* const y = static_cast<TO*>(p.y) + row0 * p.ldo + p.o_col0 + n8;
   TO* const tee = TEE ? static_cast<TO*>(p.tee) + row0 * p.ldt + (n8 - p.tee_lo) : nullptr;
@@ -129,6 +132,19 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[i][e] = fmaxf(v[i][e] + b8[e], lo) * s8[e] + h8[e];
       SdOut<TO>::store8(y + (size_t)(c0 + i) * RPP * p.ldo, v[i]);
+      if (STAT) {
+        // column statistics of this thread's rows, split at the segment boundary rb (tile-relative);
+        // taken about the pivot h8 (the BatchNorm shift) so that sum((x - pivot)^2) does not cancel
+        const bool second = rr0 + (c0 + i) * RPP >= rb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = v[i][e] - h8[e];
+          st[0][e] += second ? 0.f : x;
+          st[1][e] += second ? x : 0.f;
+          st[2][e] += second ? 0.f : x * x;
+          st[3][e] += second ? x * x : 0.f;
+        }
+      }
     }
     if (TEE) {
 #pragma unroll
@@ -137,6 +153,7 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
         SdOut<TO>::store8(tee + (size_t)(c0 + i) * RPP * p.ldt, v[i]);
       }
     }
+    if (STAT) __builtin_amdgcn_sched_barrier(0);   // keep the next chunk's LDS reads from being hoisted (register budget)
   }
 }
 
@@ -151,6 +168,7 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
   constexpr int RPP = NT / TPR;     // rows per pass
   constexpr int PASSES = ROWS / RPP;
   static_assert(ROWS % RPP == 0, "tile rows must be a multiple of the rows covered per pass");
+  static_assert(4 * RPP * COLS <= ROWS * COLS, "column statistics are combined inside the C tile");
   if (!vec || m0 + ROWS > p.M) {
     sd_store_tile_scalar<TO, ROWS, COLS, NT>(p, Cs, ldc, m0, n0, tid);
     return;
@@ -199,10 +217,38 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
 
   const bool tee_q = p.tee && n8 >= p.tee_lo && n8 < p.tee_hi;   // ranges are multiples of 8
   const size_t row0 = (size_t)(m0 + rr0);
+  if (p.colstat) {
+    // (host: only with relu / identity, a per-channel bias, cout % COLS == 0 and T >= ROWS, so this
+    // branch is uniform over the workgroup, nobody returned above, and a tile spans <= 2 segments)
+    float st[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) st[k][e] = 0.f;
+    const int rb = p.T - m0 % p.T;          // first tile row of the next segment (>= ROWS: none)
+    sd_store_rows<TO, PASSES, RPP, false, false, true>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, rb, st);   // (host: no tee with colstat)
+    // combine the RPP row groups through LDS in a fixed order, then one writer per (quantity, column)
+    __syncthreads();                        // every thread has consumed its part of the C tile
+    float* red = Cs;                        // [4][RPP][COLS]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) SdOut<float>::store8(red + ((size_t)k * RPP + rr0) * COLS + cq, st[k]);
+    __syncthreads();
+    float* dst = p.colstat + (size_t)(m0 / ROWS) * 4 * p.cout + n0;
+    for (int idx = tid; idx < 4 * COLS; idx += NT) {
+      const int k = idx / COLS, col = idx - k * COLS;
+      float a = 0.f;
+#pragma unroll
+      for (int g = 0; g < RPP; ++g) a += red[((size_t)k * RPP + g) * COLS + col];
+      dst[(size_t)k * p.cout + col] = a;
+    }
+    __syncthreads();                        // the caller may refill the tile
+    return;
+  }
+  float (*nost)[8] = nullptr;
   if (tee_q) {
-    if (TEE_MODE == 2 && p.tee_add) sd_store_rows<TO, PASSES, RPP, true, (TEE_MODE == 2)>(p, c, ldc, row0, n8, b8, s8, h8, lo);
-    else sd_store_rows<TO, PASSES, RPP, true, false>(p, c, ldc, row0, n8, b8, s8, h8, lo);
+    if (TEE_MODE == 2 && p.tee_add) sd_store_rows<TO, PASSES, RPP, true, (TEE_MODE == 2), false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, 0, nost);
+    else sd_store_rows<TO, PASSES, RPP, true, false, false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, 0, nost);
   } else {
-    sd_store_rows<TO, PASSES, RPP, false, false>(p, c, ldc, row0, n8, b8, s8, h8, lo);
+    sd_store_rows<TO, PASSES, RPP, false, false, false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, 0, nost);
   }
 }

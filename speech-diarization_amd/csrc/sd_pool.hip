@@ -315,6 +315,43 @@ int check_cl_dt(const char* fn, const void* x, int dtype, int ld, int col0, int 
   SD_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & (dtype == SD_DT_F16 ? 7u : 15u)) == 0, "%s: input is not aligned for 4-channel accesses", fn);
   return SD_OK;
 }
+// Column statistics left by the conv epilogue (sd_conv_args.colstat) -> per-segment mean (and std).
+// colstat [units][4][C]: sums of (y - pivot) and (y - pivot)^2 over each full 128-row tile, split at the
+// segment boundary inside the tile.  Thread = (segment, channel); the tiles of a segment are added in
+// ascending order, rows past the last full tile are read from y.
+template <typename T>
+__global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __restrict__ cs, const float* __restrict__ pivot,
+                                                             const T* __restrict__ y, int ldy, int Tn, int C, int M,
+                                                             int want_std, float eps, float* __restrict__ out) {
+  const int cblocks = (C + 255) / 256;
+  const int c = (blockIdx.x % cblocks) * 256 + threadIdx.x;
+  const int b = blockIdx.x / cblocks;
+  if (c >= C) return;
+  const int r0 = b * Tn, r1 = r0 + Tn;            // rows of this segment
+  const int full_units = M / 128;
+  const float pv = pivot ? pivot[c] : 0.f;
+  float s = 0.f, q = 0.f;
+  for (int u = r0 / 128; u * 128 < r1; ++u) {
+    if (u < full_units) {
+      const int part = (u * 128) / Tn == b ? 0 : 1;   // this segment is the tile's first or second
+      const float* t = cs + (size_t)u * 4 * C + c;
+      s += t[(size_t)part * C];
+      q += t[(size_t)(2 + part) * C];
+    } else {
+      const int lo = u * 128 > r0 ? u * 128 : r0;
+      for (int m = lo; m < r1; ++m) {
+        const float x = (float)y[(size_t)m * ldy + c] - pv;
+        s += x;
+        q += x * x;
+      }
+    }
+  }
+  const float inv = 1.f / (float)Tn;
+  const float m1 = s * inv;
+  out[(size_t)b * (want_std ? 2 : 1) * C + c] = pv + m1;
+  if (want_std) out[(size_t)b * 2 * C + C + c] = sqrtf(fmaxf(q * inv - m1 * m1, eps));
+}
+
 }  // namespace
 
 extern "C" int sd_seg_mean_std_dt(const void* x, int x_dtype, int ld, int col0, int B, int T, int C, int want_std, float eps,
@@ -369,6 +406,31 @@ extern "C" int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate
 extern "C" int sd_se_scale_residual_f32(const float* x, int ldx, const float* gate, const float* res, int ldr, int r_col0,
                                         float* y, int ldy, int y_col0, int B, int T, int C, sd_stream_t stream) {
   return sd_se_scale_residual_dt(x, ldx, gate, res, ldr, r_col0, y, ldy, y_col0, B, T, C, SD_DT_F32, stream);
+}
+
+extern "C" size_t sd_colstat_floats(int M, int cout) {
+  if (M <= 0 || cout <= 0) return 0;
+  return (size_t)((M + 127) / 128) * 4 * (size_t)cout;
+}
+
+extern "C" int sd_colstat_finish_dt(const float* colstat, const float* pivot, const void* y, int y_dtype, int ldy, int y_col0,
+                                    int B, int T, int C, int want_std, float eps, float* out, sd_stream_t stream) {
+  SD_CHECK_ARG(colstat && y && out, "sd_colstat_finish_dt: null pointer");
+  SD_CHECK_ARG(y_dtype == SD_DT_F32 || y_dtype == SD_DT_F16, "sd_colstat_finish_dt: y_dtype=%d", y_dtype);
+  SD_CHECK_ARG(B >= 0 && T >= 128 && C > 0, "sd_colstat_finish_dt: B=%d T=%d (>= 128) C=%d", B, T, C);
+  SD_CHECK_ARG((long)B * T < (1L << 31) && y_col0 >= 0 && y_col0 + C <= ldy, "sd_colstat_finish_dt: bad shape");
+  if (B == 0) return SD_OK;
+  SD_CHECK_ARG((long)B * ((C + 255) / 256) < (1L << 31), "sd_colstat_finish_dt: grid too large");
+  const dim3 grid((unsigned)((long)B * ((C + 255) / 256)));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (y_dtype == SD_DT_F16)
+    hipLaunchKernelGGL(colstat_finish_kernel<_Float16>, grid, dim3(256), 0, s, colstat, pivot, static_cast<const _Float16*>(y) + y_col0, ldy, T, C,
+                       B * T, want_std, eps, out);
+  else
+    hipLaunchKernelGGL(colstat_finish_kernel<float>, grid, dim3(256), 0, s, colstat, pivot, static_cast<const float*>(y) + y_col0, ldy, T, C,
+                       B * T, want_std, eps, out);
+  SD_CHECK_LAUNCH("colstat_finish_kernel");
+  return SD_OK;
 }
 
 extern "C" int sd_asp_pool_dt(const void* logit, int ldl, const void* h, int dtype, int ldh, int B, int T, int C, float eps,

@@ -50,11 +50,13 @@ def _dt(t: torch.dtype) -> int:
 def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, T: int, *, cin: int, dil: int = 1, bias=None, bias_per_seg=False,
               act=None, scale=None, shift=None, act2=None, a_col0: int = 0, out: torch.Tensor | None = None,
               o_col0: int = 0, tee: torch.Tensor | None = None, tee_lo: int = 0, tee_hi: int = 0,
-              tee_add: torch.Tensor | None = None, ta_col0: int = 0, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+              tee_add: torch.Tensor | None = None, ta_col0: int = 0, out_dtype: torch.dtype | None = None,
+              colstat: torch.Tensor | None = None) -> torch.Tensor:
     """Channel-last conv1d ("same", reflect) with the fused TDNN epilogue. x: [M, lda], returns [M, ldo].
     f32 weights -> exact-f32 operator; f16 weights -> f16-operand / f32-accumulate operator (x f32 or
-    f16, output `out_dtype`)."""
-    _need_cuda(x, w_packed, bias, scale, shift, out, tee, tee_add)
+    f16, output `out_dtype`).  `colstat` (f32, `colstat_floats(M, cout)` elements) receives the epilogue's
+    per-tile column sums for `colstat_finish`."""
+    _need_cuda(x, w_packed, bias, scale, shift, out, tee, tee_add, colstat)
     lib = N.load()
     cout, taps, cin_pad = w_packed.shape
     M = x.shape[0]
@@ -78,9 +80,30 @@ def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, T: int, *, cin: int, dil:
         a.tee, a.ldt, a.tee_lo, a.tee_hi = tee.data_ptr(), tee.stride(0), tee_lo, tee_hi
         if tee_add is not None:
             a.tee_add, a.ld_ta, a.ta_col0 = tee_add.data_ptr(), tee_add.stride(0), ta_col0
+    if colstat is not None:
+        if colstat.dtype != torch.float32 or colstat.numel() < colstat_floats(M, cout):
+            raise ValueError("colstat must be f32 with colstat_floats(M, cout) elements")
+        a.colstat = colstat.data_ptr()
     with torch.cuda.device(x.device):
         fn, name = (lib.sd_conv1d_cl_f16, "sd_conv1d_cl_f16") if half else (lib.sd_conv1d_cl_f32, "sd_conv1d_cl_f32")
         N.check(fn(C.byref(a), _stream(x)), name)
+    return out
+
+
+def colstat_floats(M: int, cout: int) -> int:
+    return int(N.load().sd_colstat_floats(M, cout))
+
+
+def colstat_finish(colstat: torch.Tensor, y: torch.Tensor, B: int, T: int, *, pivot: torch.Tensor | None = None, want_std: bool = False,
+                   eps: float = 1e-12, y_col0: int = 0, C_: int | None = None) -> torch.Tensor:
+    """Per-segment mean (and std) of a conv output from the column sums its epilogue left in `colstat`
+    (`pivot` = the conv's `shift`, or None).  -> f32 [B, C] or [B, 2C] = [mean | std]."""
+    _need_cuda(colstat, y, pivot)
+    C_ = y.shape[1] - y_col0 if C_ is None else C_
+    out = torch.empty((B, (2 if want_std else 1) * C_), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        N.check(N.load().sd_colstat_finish_dt(colstat.data_ptr(), _ptr(pivot), y.data_ptr(), _dt(y.dtype), y.stride(0), y_col0, B, T, C_,
+                                              int(want_std), C.c_float(eps), out.data_ptr(), _stream(y)), "sd_colstat_finish_dt")
     return out
 
 

@@ -132,6 +132,44 @@ def test_fused_attention_pooling_refuses_what_it_does_not_cover(dev):
                             torch.zeros(300, 256, device=dev, dtype=torch.float16), 1, 300)
 
 
+@pytest.mark.parametrize("wdt,B,T,cin,cout", [
+    (torch.float32, 5, 201, 64, 256),      # f32 kernel, partial last tile (1005 rows)
+    (torch.float32, 4, 128, 32, 512),      # tiles aligned with segments
+    (torch.float16, 5, 201, 64, 256),      # register-staged f16 kernel
+    (torch.float16, 3, 150, 64, 1024),     # 256x256 f16 kernel (two 128-row halves per tile)
+    (torch.float16, 7, 301, 128, 1024),
+])
+def test_epilogue_column_statistics(dev, wdt, B, T, cin, cout):
+    """SE squeeze mean / global mean+std straight from the conv epilogue == statistics of the stored output."""
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(T * 7 + cout)
+    M = B * T
+    x = torch.randn(M, cin, generator=g).to(wdt)
+    w = torch.randn(cout, cin, 1, generator=g) / np.sqrt(cin)
+    bias, scale, shift = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 2
+    cs = torch.full((ops.colstat_floats(M, cout),), float("nan"), device=dev)
+    y = ops.conv1d_cl(x.to(dev), ops.pack_weight(w, dev, wdt), T, cin=cin, bias=bias.to(dev), act="relu", scale=scale.to(dev),
+                      shift=shift.to(dev), colstat=cs)
+    y_plain = ops.conv1d_cl(x.to(dev), ops.pack_weight(w, dev, wdt), T, cin=cin, bias=bias.to(dev), act="relu", scale=scale.to(dev),
+                            shift=shift.to(dev))
+    assert torch.equal(y, y_plain)                                   # the stored output does not change
+    st = ops.colstat_finish(cs, y, B, T, pivot=shift.to(dev), want_std=True).cpu().double()
+    mean_only = ops.colstat_finish(cs, y, B, T, pivot=shift.to(dev)).cpu().double()
+    yr = y.cpu().double().view(B, T, cout)
+    tol = 2e-5 if wdt == torch.float32 else 2e-3                     # f16: statistics of the UNROUNDED outputs vs the rounded store
+    assert (st[:, :cout] - yr.mean(1)).abs().max() < tol
+    assert (st[:, cout:] - yr.std(1, unbiased=False)).abs().max() < tol
+    assert torch.equal(mean_only, st[:, :cout])
+
+
+def test_epilogue_column_statistics_refuses_short_segments(dev):
+    from speech_diarization_amd import ops
+    x = torch.zeros(3 * 64, 64, device=dev)
+    w = ops.pack_weight(torch.zeros(256, 64, 1), dev)
+    with pytest.raises(RuntimeError, match="colstat needs"):
+        ops.conv1d_cl(x, w, 64, cin=64, act="relu", colstat=torch.zeros(ops.colstat_floats(192, 256), device=dev))
+
+
 def test_pool_kernels_on_f16_activations(dev):
     import ctypes as C
     from speech_diarization_amd import _native as N
