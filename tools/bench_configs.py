@@ -39,6 +39,40 @@ def stream_latency(state_dict, dev, precision, use_graph, hops):
             "hops_per_s": float(1e3 / lat.mean()), "realtime_factor_16ch": float(250.0 / np.percentile(lat, 99))}
 
 
+def host_api_rate(batch, n=32000, reps=20):
+    """The reference's own call: numpy in -> numpy out (H2D + fbank + ECAPA + D2H per call), f32 engine."""
+    from speech_diarization_amd import speech_encode, synth
+    wavs = synth.synthetic_segments(5, batch, n)
+    speech_encode.ecapa_encode_batch(wavs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        speech_encode.ecapa_encode_batch(wavs)
+    dt = time.perf_counter() - t0
+    return {"batch": batch, "segments_per_s": batch * reps / dt, "ms_per_call": dt / reps * 1e3}
+
+
+def micro_batch_sweep(state_dict, dev, precision):
+    """Resident throughput vs micro-batch ({32, 128, 512, 2048}) on 4096 segments."""
+    from speech_diarization_amd.engine import EmbeddingEngine
+    wav = (torch.randn(4096, 32000, device=dev) * 0.1).clamp_(-1, 1)
+    out = []
+    for mb in (32, 128, 512, 2048):
+        eng = EmbeddingEngine(state_dict, dev, max_batch=mb, precision=precision)
+        eng.embed(wav)
+        torch.cuda.synchronize()
+        best = float("inf")
+        for _ in range(2):
+            t0 = time.perf_counter()
+            eng.embed(wav)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        out.append({"micro_batch": mb, "segments_per_s": 4096 / best})
+        del eng
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--hops", type=int, default=200)
@@ -58,6 +92,8 @@ def main():
         torch.cuda.synchronize()
         t.append(time.perf_counter() - t0)
     dt = min(t)
+    out["micro_batch_sweep"] = {p: micro_batch_sweep(sd, dev, p) for p in ("f32", "f16")}
+    out["host_api_numpy_in_out_f32"] = [host_api_rate(b) for b in (32, 128)]
     out["affinity_50k"] = {"ms": dt * 1e3, "tflops": 384.0 * 50000 ** 2 / dt / 1e12, "write_tb_s": 4.0 * 50000 ** 2 / dt / 1e12}
     print(json.dumps(out))
 
