@@ -132,9 +132,9 @@ typedef struct {
   int x_dtype; int y_dtype; /* SD_DT_*; 0 = f32 (the only choice for sd_conv1d_cl_f32) */
   /* Optional per-segment column statistics from the epilogue (the SE squeeze mean, the global mean / std
    * of attentive pooling), so that y is not read back for them.  colstat: [ceil(M / 128)][4][cout] floats;
-   * for every full 128-row tile, sums over its rows of (y - shift) and (y - shift)^2, split at the segment
-   * boundary inside the tile: [sum first | sum second | sumsq first | sumsq second].  sd_colstat_finish_dt
-   * turns them into [mean | std] per segment (and reads the rows of a trailing partial tile itself).
+   * for every 128-row tile, sums over its (existing) rows of (y - shift) and (y - shift)^2, split at the
+   * segment boundary inside the tile: [sum first | sum second | sumsq first | sumsq second].
+   * sd_colstat_finish_dt turns them into [mean | std] per segment.
    * Requirements (SD_ERR_UNSUPPORTED otherwise): T >= 128, cout a multiple of 256, relu / identity
    * activation, per-channel bias, 16-byte aligned slices, no tee. */
   float* colstat;
@@ -144,7 +144,7 @@ int sd_conv1d_cl_f32(const sd_conv_args* args, sd_stream_t stream);
 int sd_conv1d_cl_f16(const sd_conv_args* args, sd_stream_t stream);
 /* floats needed for sd_conv_args.colstat */
 size_t sd_colstat_floats(int M, int cout);
-/* colstat (+ the rows of y past the last full 128-row tile) -> out [B][C] = mean (want_std = 0) or
+/* colstat -> out [B][C] = mean (want_std = 0) or
  * [B][2*C] = [mean | sqrt(clamp(var, eps))]; pivot = the conv's shift vector (NULL = 0); y [B*T][ldy]
  * of y_dtype at column y_col0 is the conv's output */
 int sd_colstat_finish_dt(const float* colstat, const float* pivot, const void* y, int y_dtype, int ldy, int y_col0,

@@ -106,10 +106,12 @@ __device__ __forceinline__ void sd_store_tile_scalar(const sd_conv_args& p, cons
 // Store phase of the vector path for a FULL tile (no row checks: straight-line code).  TEE adds
 // the Res2Net copy of a channel range; TADD also adds another tensor's rows to that copy, which
 // are all fetched before the first store (so the rows cannot go out in small chunks).
-template <typename TO, int PASSES, int RPP, bool TEE, bool TADD, bool STAT>
+// FULL: every row of the tile exists (straight-line code); otherwise the thread's first `np` passes
+// do (the tile hangs over row M) and the rest are predicated off.
+template <typename TO, int PASSES, int RPP, bool TEE, bool TADD, bool STAT, bool FULL>
 __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float* c, int ldc, size_t row0, int n8,
                                               const float* b8, const float* s8, const float* h8, float lo,
-                                              int rr0, int rb, float (*st)[8]) {
+                                              int rr0, int rb, float (*st)[8], int np) {
   // rows per fetch/store chunk: all of them when tee_add rows must be prefetched; 1 with the 32 statistics
   // accumulators live (the 256x256 kernel has 128 VGPRs beside its accumulators); else 4
   constexpr int CH = TADD ? PASSES : (STAT ? 1 : (PASSES < 4 ? PASSES : 4));
@@ -125,20 +127,24 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
     typename SdOut<TO>::raw8 t[CH];
     if (TADD) {
 #pragma unroll
-      for (int i = 0; i < CH; ++i) t[i] = SdOut<TO>::load_raw(ta + (size_t)(c0 + i) * RPP * p.ld_ta);
+      for (int i = 0; i < CH; ++i) {
+        const int ps = FULL ? c0 + i : (c0 + i < np ? c0 + i : (np > 0 ? np - 1 : 0));   // stay inside the tensor
+        t[i] = SdOut<TO>::load_raw(ta + (size_t)ps * RPP * p.ld_ta);
+      }
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[i][e] = fmaxf(v[i][e] + b8[e], lo) * s8[e] + h8[e];
-      SdOut<TO>::store8(y + (size_t)(c0 + i) * RPP * p.ldo, v[i]);
+      const bool live = FULL || c0 + i < np;
+      if (live) SdOut<TO>::store8(y + (size_t)(c0 + i) * RPP * p.ldo, v[i]);
       if (STAT) {
         // column statistics of this thread's rows, split at the segment boundary rb (tile-relative);
         // taken about the pivot h8 (the BatchNorm shift) so that sum((x - pivot)^2) does not cancel
         const bool second = rr0 + (c0 + i) * RPP >= rb;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float x = v[i][e] - h8[e];
+          const float x = live ? v[i][e] - h8[e] : 0.f;
           st[0][e] += second ? 0.f : x;
           st[1][e] += second ? x : 0.f;
           st[2][e] += second ? 0.f : x * x;
@@ -150,7 +156,7 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         if (TADD) SdOut<TO>::add_raw(v[i], t[i]);
-        SdOut<TO>::store8(tee + (size_t)(c0 + i) * RPP * p.ldt, v[i]);
+        if (FULL || c0 + i < np) SdOut<TO>::store8(tee + (size_t)(c0 + i) * RPP * p.ldt, v[i]);
       }
     }
     if (STAT) __builtin_amdgcn_sched_barrier(0);   // keep the next chunk's LDS reads from being hoisted (register budget)
@@ -159,7 +165,9 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
 
 // ROWS x COLS tile at (m0, n0); NT threads; vec != 0 when every touched row slice and the
 // per-channel parameter vectors are 16-byte aligned and cout / column offsets are multiples of 8
-// (decided on the host).  A tile that hangs over the last row takes the element-wise fallback.
+// (decided on the host).  A tile that hangs over the last row runs the same code with its missing rows
+// predicated off (an element-wise path there made the one straggling workgroup the critical path of
+// small launches: a 32-segment batch has 50.25 row tiles).
 // TEE_MODE: 2 = full (tee with or without tee_add), 1 = tee without tee_add only (the host never
 // selects such a kernel for a tee_add layer; saves the registers of the prefetched rows).
 template <typename TO, int ROWS, int COLS, int NT, int TEE_MODE = 2>
@@ -169,10 +177,12 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
   constexpr int PASSES = ROWS / RPP;
   static_assert(ROWS % RPP == 0, "tile rows must be a multiple of the rows covered per pass");
   static_assert(4 * RPP * COLS <= ROWS * COLS, "column statistics are combined inside the C tile");
-  if (!vec || m0 + ROWS > p.M) {
+  if (!vec) {
     sd_store_tile_scalar<TO, ROWS, COLS, NT>(p, Cs, ldc, m0, n0, tid);
     return;
   }
+  const int nrows = p.M - m0 < ROWS ? p.M - m0 : ROWS;     // rows of this tile that exist (> 0)
+  const bool full = nrows == ROWS;
   const int cq = (tid % TPR) * 8;
   const int n8 = n0 + cq;
   const int rr0 = tid / TPR;
@@ -193,6 +203,7 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
     // tile (every thread rewrites exactly the slots it reads back below: no barrier needed)
 #pragma unroll 1
     for (int ps = 0; ps < PASSES; ++ps) {
+      if (rr0 + ps * RPP >= nrows) break;
       float* cr = c + ps * RPP * ldc;
       float v[8];
       SdOut<float>::load8(cr, v);
@@ -216,17 +227,43 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
   }
 
   const bool tee_q = p.tee && n8 >= p.tee_lo && n8 < p.tee_hi;   // ranges are multiples of 8
-  const size_t row0 = (size_t)(m0 + rr0);
+  const int np = rr0 < nrows ? (nrows - rr0 + RPP - 1) / RPP : 0;             // this thread's existing rows
+  const size_t row0 = (size_t)(m0 + (rr0 < nrows ? rr0 : 0));
+#define SD_ROWS(TEE_, TADD_, STAT_, ST_, RB_)                                                                            \
+  do {                                                                                                                   \
+    if (full) sd_store_rows<TO, PASSES, RPP, TEE_, TADD_, STAT_, true>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, RB_, ST_, PASSES); \
+    else sd_store_rows<TO, PASSES, RPP, TEE_, TADD_, STAT_, false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, RB_, ST_, np);        \
+  } while (0)
   if (p.colstat) {
-    // (host: only with relu / identity, a per-channel bias, cout % COLS == 0 and T >= ROWS, so this
-    // branch is uniform over the workgroup, nobody returned above, and a tile spans <= 2 segments)
+    // (host: only with relu / identity, a per-channel bias, cout % COLS == 0, no tee and T >= ROWS, so
+    // this branch is uniform over the workgroup, nobody returned above, and a tile spans <= 2 segments)
     float st[4][8];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int e = 0; e < 8; ++e) st[k][e] = 0.f;
     const int rb = p.T - m0 % p.T;          // first tile row of the next segment (>= ROWS: none)
-    sd_store_rows<TO, PASSES, RPP, false, false, true>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, rb, st);   // (host: no tee with colstat)
+    if (full) {
+      sd_store_rows<TO, PASSES, RPP, false, false, true, true>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, rb, st, PASSES);
+    } else {
+      // the one tile that hangs over row M: predicated stores, then a rolled pass over this thread's
+      // existing rows for the statistics (keeps the unrolled variant's registers out of the common path)
+      sd_store_rows<TO, PASSES, RPP, false, false, false, false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, 0, nullptr, np);
+#pragma unroll 1
+      for (int ps = 0; ps < np; ++ps) {
+        float v[8];
+        SdOut<float>::load8(c + ps * RPP * ldc, v);
+        const bool second = rr0 + ps * RPP >= rb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = fmaxf(v[e] + b8[e], lo) * s8[e];     // = y - shift
+          st[0][e] += second ? 0.f : x;
+          st[1][e] += second ? x : 0.f;
+          st[2][e] += second ? 0.f : x * x;
+          st[3][e] += second ? x * x : 0.f;
+        }
+      }
+    }
     // combine the RPP row groups through LDS in a fixed order, then one writer per (quantity, column)
     __syncthreads();                        // every thread has consumed its part of the C tile
     float* red = Cs;                        // [4][RPP][COLS]
@@ -246,9 +283,10 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
   }
   float (*nost)[8] = nullptr;
   if (tee_q) {
-    if (TEE_MODE == 2 && p.tee_add) sd_store_rows<TO, PASSES, RPP, true, (TEE_MODE == 2), false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, 0, nost);
-    else sd_store_rows<TO, PASSES, RPP, true, false, false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, 0, nost);
+    if (TEE_MODE == 2 && p.tee_add) SD_ROWS(true, (TEE_MODE == 2), false, nost, 0);
+    else SD_ROWS(true, false, false, nost, 0);
   } else {
-    sd_store_rows<TO, PASSES, RPP, false, false, false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, 0, nost);
+    SD_ROWS(false, false, false, nost, 0);
   }
+#undef SD_ROWS
 }

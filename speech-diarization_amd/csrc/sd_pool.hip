@@ -317,8 +317,8 @@ int check_cl_dt(const char* fn, const void* x, int dtype, int ld, int col0, int 
 }
 // Column statistics left by the conv epilogue (sd_conv_args.colstat) -> per-segment mean (and std).
 // colstat [units][4][C]: sums of (y - pivot) and (y - pivot)^2 over each full 128-row tile, split at the
-// segment boundary inside the tile.  Thread = (segment, channel); the tiles of a segment are added in
-// ascending order, rows past the last full tile are read from y.
+// segment boundary inside the tile (a trailing partial tile counts its existing rows).  Thread =
+// (segment, channel); the tiles of a segment are added in ascending order.
 template <typename T>
 __global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __restrict__ cs, const float* __restrict__ pivot,
                                                              const T* __restrict__ y, int ldy, int Tn, int C, int M,
@@ -328,23 +328,13 @@ __global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __rest
   const int b = blockIdx.x / cblocks;
   if (c >= C) return;
   const int r0 = b * Tn, r1 = r0 + Tn;            // rows of this segment
-  const int full_units = M / 128;
   const float pv = pivot ? pivot[c] : 0.f;
   float s = 0.f, q = 0.f;
   for (int u = r0 / 128; u * 128 < r1; ++u) {
-    if (u < full_units) {
-      const int part = (u * 128) / Tn == b ? 0 : 1;   // this segment is the tile's first or second
-      const float* t = cs + (size_t)u * 4 * C + c;
-      s += t[(size_t)part * C];
-      q += t[(size_t)(2 + part) * C];
-    } else {
-      const int lo = u * 128 > r0 ? u * 128 : r0;
-      for (int m = lo; m < r1; ++m) {
-        const float x = (float)y[(size_t)m * ldy + c] - pv;
-        s += x;
-        q += x * x;
-      }
-    }
+    const int part = (u * 128) / Tn == b ? 0 : 1;   // this segment is the tile's first or second
+    const float* t = cs + (size_t)u * 4 * C + c;
+    s += t[(size_t)part * C];
+    q += t[(size_t)(2 + part) * C];
   }
   const float inv = 1.f / (float)Tn;
   const float m1 = s * inv;
