@@ -181,7 +181,8 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
     sd_store_tile_scalar<TO, ROWS, COLS, NT>(p, Cs, ldc, m0, n0, tid);
     return;
   }
-  const int nrows = p.M - m0 < ROWS ? p.M - m0 : ROWS;     // rows of this tile that exist (> 0)
+  const int nrows = p.M - m0 < ROWS ? p.M - m0 : ROWS;     // rows of this tile that exist
+  if (nrows <= 0) return;            // second half of a 256-row tile that starts past the last row (uniform)
   const bool full = nrows == ROWS;
   const int cq = (tid % TPR) * 8;
   const int n8 = n0 + cq;

@@ -137,7 +137,8 @@ def test_fused_attention_pooling_refuses_what_it_does_not_cover(dev):
     (torch.float32, 4, 128, 32, 512),      # tiles aligned with segments
     (torch.float16, 5, 201, 64, 256),      # register-staged f16 kernel
     (torch.float16, 3, 150, 64, 1024),     # 256x256 f16 kernel (two 128-row halves per tile)
-    (torch.float16, 7, 301, 128, 1024),
+    (torch.float16, 7, 301, 128, 1024),    # last 256-row tile: second half starts past the last row
+    (torch.float16, 3, 201, 64, 1024),
 ])
 def test_epilogue_column_statistics(dev, wdt, B, T, cin, cout):
     """SE squeeze mean / global mean+std straight from the conv epilogue == statistics of the stored output."""
@@ -147,12 +148,14 @@ def test_epilogue_column_statistics(dev, wdt, B, T, cin, cout):
     x = torch.randn(M, cin, generator=g).to(wdt)
     w = torch.randn(cout, cin, 1, generator=g) / np.sqrt(cin)
     bias, scale, shift = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 2
-    cs = torch.full((ops.colstat_floats(M, cout),), float("nan"), device=dev)
+    n_cs = ops.colstat_floats(M, cout)
+    cs = torch.full((n_cs + 8192,), float("nan"), device=dev)          # guard words behind the buffer
     y = ops.conv1d_cl(x.to(dev), ops.pack_weight(w, dev, wdt), T, cin=cin, bias=bias.to(dev), act="relu", scale=scale.to(dev),
                       shift=shift.to(dev), colstat=cs)
     y_plain = ops.conv1d_cl(x.to(dev), ops.pack_weight(w, dev, wdt), T, cin=cin, bias=bias.to(dev), act="relu", scale=scale.to(dev),
                             shift=shift.to(dev))
     assert torch.equal(y, y_plain)                                   # the stored output does not change
+    assert bool(torch.isfinite(cs[:n_cs]).all()) and bool(torch.isnan(cs[n_cs:]).all())   # every tile wrote, nobody wrote past the end
     st = ops.colstat_finish(cs, y, B, T, pivot=shift.to(dev), want_std=True).cpu().double()
     mean_only = ops.colstat_finish(cs, y, B, T, pivot=shift.to(dev)).cpu().double()
     yr = y.cpu().double().view(B, T, cout)
