@@ -35,8 +35,8 @@ static_assert(BM * LDC <= 2 * (BM + BN) * LDP, "C tile must fit in the operand s
 __device__ unsigned long long sd_c32_stamp_buf[8192 * 10];
 #endif
 
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p, const int vec, const int order) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// one 128x128 output tile
+__device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int vec, const int tile_m, const int tile_n, float* smem) {
 #ifdef SD_STAMP
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
@@ -47,31 +47,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-
-  // Workgroups are dealt round-robin over the eight XCDs (one 4 MB L2 each).  A bijective remap
-  // first gives every XCD a contiguous range of logical workgroups; those are then laid out in
-  // bands of 8 row tiles, n-major inside a band, so the ~64 workgroups an XCD runs at a time form
-  // an 8 x 8 patch of tiles: each A row panel and each weight column panel it touches is shared
-  // by 8 workgroups.  Measured: L2 fill traffic of the C->C layers 13.6 -> 8.8 GB per launch
-  // (A alone is 1.7 GB; workgroups drift apart in K, so whole panels would have to stay resident
-  // for more), throughput unchanged within the box-to-box noise (the kernel is MFMA bound).
-  // SD_TILE_ORDER=0 (host, diagnostic) keeps the launch order.
-  const int n_tiles = (p.cout + BN - 1) / BN;
-  int tile_m, tile_n;
-  if (order == 0) {
-    tile_n = blockIdx.x % n_tiles;
-    tile_m = blockIdx.x / n_tiles;
-  } else {
-    const int nwg = gridDim.x, bx = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bx & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
-    const int m_tiles = nwg / n_tiles;
-    const int band = wg / (8 * n_tiles);
-    const int in_band = wg - band * 8 * n_tiles;
-    const int rows = m_tiles - band * 8 < 8 ? m_tiles - band * 8 : 8;
-    tile_n = in_band / rows;
-    tile_m = band * 8 + in_band % rows;
-  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // staging role: 8 threads per 32-float row, 4 rows per thread.  Rows past M and output
@@ -258,6 +233,40 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
 #endif
 }
 
+// One workgroup per tile (the grid may be smaller, SD_PERSIST: the workgroups then walk the tile list).
+//
+// Workgroups are dealt round-robin over the eight XCDs (one 4 MB L2 each).  Every XCD owns a
+// contiguous range of logical tiles, laid out in bands of 8 row tiles, n-major inside a band, so
+// the ~64 workgroups an XCD runs at a time form an 8 x 8 patch of tiles: each A row panel and each
+// weight column panel it touches is shared by 8 workgroups.  Measured: L2 fill traffic of the C->C
+// layers 13.6 -> 8.8 GB per launch (A alone is 1.7 GB; workgroups drift apart in K, so whole panels
+// would have to stay resident for more), throughput unchanged within the box-to-box noise (the
+// kernel is MFMA bound).  SD_TILE_ORDER=0 (host, diagnostic) keeps the launch order.
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p, const int vec, const int order, const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n_tiles = (p.cout + BN - 1) / BN;
+  if (order == 0) {
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      conv_tile_f32(p, vec, t / n_tiles, t % n_tiles, smem);
+      __syncthreads();              // the next tile refills the LDS stage the epilogue was reading
+    }
+    return;
+  }
+  const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7;
+  const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;   // this XCD's logical tiles
+  const int count = q + (xcd < r ? 1 : 0);
+  const int peers = ((int)gridDim.x - xcd + 7) >> 3;                          // workgroups dealt to this XCD
+  const int m_tiles = ntiles / n_tiles;
+  for (int i = blockIdx.x >> 3; i < count; i += peers) {
+    const int wg = first + i;
+    const int band = wg / (8 * n_tiles);
+    const int in_band = wg - band * 8 * n_tiles;
+    const int rows = m_tiles - band * 8 < 8 ? m_tiles - band * 8 : 8;
+    conv_tile_f32(p, vec, band * 8 + in_band % rows, in_band / rows, smem);
+    __syncthreads();
+  }
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Per-segment layers (SE squeeze/excite, global-context bias, final FC): M = B rows only, so the
@@ -385,11 +394,20 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
     const char* e = getenv("SD_TILE_ORDER");
     return e ? atoi(e) : 1;
   }();
+  // SD_PERSIST=<n> (diagnostic): at most n workgroups walk the tile list instead of one workgroup per
+  // tile.  Measured with n = 2 per CU: 2.3 % SLOWER (the dispatcher's dynamic placement beats a static
+  // share of the tiles; dispatch gaps are not what separates the kernel from its K-loop rate).
+  static const int persist = [] {
+    const char* e = getenv("SD_PERSIST");
+    return e ? atoi(e) : 0;
+  }();
   {
     SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream),
                      2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
-    hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds,
-                       static_cast<hipStream_t>(stream), *a, vec, order);
+    const long ntiles = tiles_m * tiles_n;
+    const long grid = (persist > 0 && ntiles > persist) ? persist : ntiles;
+    hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3((unsigned)grid), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), *a, vec, order, (int)ntiles);
   }
   SD_CHECK_LAUNCH("conv_gemm_f32_kernel");
   return SD_OK;

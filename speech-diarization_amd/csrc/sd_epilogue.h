@@ -112,26 +112,27 @@ template <typename TO, int PASSES, int RPP, bool TEE, bool TADD, bool STAT, bool
 __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float* c, int ldc, size_t row0, int n8,
                                               const float* b8, const float* s8, const float* h8, float lo,
                                               int rr0, int rb, float (*st)[8], int np) {
-  // rows per fetch/store chunk: all of them when tee_add rows must be prefetched; 1 with the 32 statistics
-  // accumulators live (the 256x256 kernel has 128 VGPRs beside its accumulators); else 4
-  constexpr int CH = TADD ? PASSES : (STAT ? 1 : (PASSES < 4 ? PASSES : 4));
+  // LDS rows are fetched and stored in chunks of 4 (1 with the 32 statistics accumulators live: the
+  // 256x256 kernel has 128 VGPRs beside its accumulators).  The tee_add rows are GLOBAL loads and must
+  // all be issued before the first store (header comment), so they are prefetched for the whole tile.
+  constexpr int CH = STAT ? 1 : (PASSES < 4 ? PASSES : 4);
   static_assert(PASSES % CH == 0 && (TEE || !TADD), "");
   TO* const y = static_cast<TO*>(p.y) + row0 * p.ldo + p.o_col0 + n8;
   TO* const tee = TEE ? static_cast<TO*>(p.tee) + row0 * p.ldt + (n8 - p.tee_lo) : nullptr;
-  const TO* const ta = TADD ? static_cast<const TO*>(p.tee_add) + row0 * p.ld_ta + p.ta_col0 + (n8 - p.tee_lo) : nullptr;
+  typename SdOut<TO>::raw8 t[TADD ? PASSES : 1];
+  if (TADD) {
+    const TO* const ta = static_cast<const TO*>(p.tee_add) + row0 * p.ld_ta + p.ta_col0 + (n8 - p.tee_lo);
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      const int ps = FULL ? i : (i < np ? i : (np > 0 ? np - 1 : 0));   // stay inside the tensor
+      t[i] = SdOut<TO>::load_raw(ta + (size_t)ps * RPP * p.ld_ta);
+    }
+  }
 #pragma unroll
   for (int c0 = 0; c0 < PASSES; c0 += CH) {
     float v[CH][8];
 #pragma unroll
     for (int i = 0; i < CH; ++i) SdOut<float>::load8(c + (c0 + i) * RPP * ldc, v[i]);
-    typename SdOut<TO>::raw8 t[CH];
-    if (TADD) {
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int ps = FULL ? c0 + i : (c0 + i < np ? c0 + i : (np > 0 ? np - 1 : 0));   // stay inside the tensor
-        t[i] = SdOut<TO>::load_raw(ta + (size_t)ps * RPP * p.ld_ta);
-      }
-    }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
 #pragma unroll
@@ -151,15 +152,12 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
           st[3][e] += second ? x * x : 0.f;
         }
       }
-    }
-    if (TEE) {
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        if (TADD) SdOut<TO>::add_raw(v[i], t[i]);
-        if (FULL || c0 + i < np) SdOut<TO>::store8(tee + (size_t)(c0 + i) * RPP * p.ldt, v[i]);
+      if (TEE) {
+        if (TADD) SdOut<TO>::add_raw(v[i], t[c0 + i]);
+        if (live) SdOut<TO>::store8(tee + (size_t)(c0 + i) * RPP * p.ldt, v[i]);
       }
     }
-    if (STAT) __builtin_amdgcn_sched_barrier(0);   // keep the next chunk's LDS reads from being hoisted (register budget)
+    if (STAT || TADD) __builtin_amdgcn_sched_barrier(0);   // keep the next chunk's LDS reads from being hoisted (register budget)
   }
 }
 
