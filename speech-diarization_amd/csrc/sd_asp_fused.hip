@@ -48,10 +48,10 @@ __device__ __forceinline__ float red16(float v) {
 }
 
 template <int TPW>   // 16-frame tiles per wave: T <= 64 * TPW
-__global__ __launch_bounds__(256, 2) void asp_attend_pool_f16_kernel(const _Float16* __restrict__ a1, const _Float16* __restrict__ wc,
+__global__ __launch_bounds__(256, 3) void asp_attend_pool_f16_kernel(const _Float16* __restrict__ a1, const _Float16* __restrict__ wc,
                                                                      const _Float16* __restrict__ h, int ldh, int Tn, int C,
                                                                      float eps, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 sw[];   // [CPB][WLD] weights; reused for the partial statistics
+  extern __shared__ __attribute__((aligned(16))) _Float16 sw[];   // [CPB / 2][WLD] weights; reused for the partial statistics
   const int cblocks = C / CPB;
   const int b = blockIdx.x / cblocks, cblk = blockIdx.x % cblocks;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -70,15 +70,16 @@ __global__ __launch_bounds__(256, 2) void asp_attend_pool_f16_kernel(const _Floa
       for (int ks = 0; ks < AK / 32; ++ks) af[j][ks] = t < Tn ? *reinterpret_cast<const h8*>(ar + ks * 32) : z;
     }
   }
-  // weight tile -> LDS
-  {
-    const _Float16* wb = wc + (size_t)cblk * CPB * AK;
+  // weight tile -> LDS, one half (128 channels, 34 KB) at a time so that three workgroups fit a CU
+  auto stage_w = [&](int half) {
+    const _Float16* wb = wc + ((size_t)cblk * CPB + half * (CPB / 2)) * AK;
 #pragma unroll 4
-    for (int p = tid; p < CPB * (AK / 8); p += 256) {
+    for (int p = tid; p < (CPB / 2) * (AK / 8); p += 256) {
       const int row = p / (AK / 8), q = (p % (AK / 8)) * 8;
       *reinterpret_cast<h8*>(sw + row * WLD + q) = *reinterpret_cast<const h8*>(wb + (size_t)row * AK + q);
     }
-  }
+  };
+  stage_w(0);
   __syncthreads();
 
   // h pointer of this lane: frame t0 + col (+16 j), channels cblk*256 + 16 g + 4 quad .. +3
@@ -99,8 +100,13 @@ __global__ __launch_bounds__(256, 2) void asp_attend_pool_f16_kernel(const _Floa
 #pragma unroll 1
   for (int g = 0; g < NG; ++g) {
     if (g + 1 < NG) load_h(g + 1, hn);
+    if (g == NG / 2) {
+      __syncthreads();              // every wave is done with the first half of the weights
+      stage_w(1);
+      __syncthreads();
+    }
     // A fragment: lane (col, quad) holds W[16 g + col][32 ks + 8 quad .. +7]
-    const _Float16* wr = sw + (g * 16 + col) * WLD + quad * 8;
+    const _Float16* wr = sw + ((g % (NG / 2)) * 16 + col) * WLD + quad * 8;
     f32x4 acc[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -179,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void asp_attend_pool_f16_kernel(const _Floa
 template <int TPW>
 int launch_f16(const void* a1, const void* wc, const void* h, int ldh, int B, int T, int C, float eps, float* out, hipStream_t s) {
   auto kern = asp_attend_pool_f16_kernel<TPW>;
-  const size_t lds = (size_t)CPB * WLD * sizeof(_Float16);
-  static_assert((size_t)CPB * WLD * sizeof(_Float16) >= (size_t)4 * CPB * 4 * sizeof(float), "statistics must fit in the weight tile");
+  const size_t lds = (size_t)(CPB / 2) * WLD * sizeof(_Float16);
+  static_assert((size_t)(CPB / 2) * WLD * sizeof(_Float16) >= (size_t)4 * CPB * 4 * sizeof(float), "statistics must fit in the weight tile");
   static bool attr_set = false;
   if (!attr_set) {
     SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
