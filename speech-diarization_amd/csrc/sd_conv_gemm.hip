@@ -29,19 +29,32 @@ constexpr int BN = 128;
 constexpr int BK = 32;
 constexpr int LDP = BK + 4;  // padded LDS row, floats
 constexpr int LDC = BN + 4;  // padded row of the epilogue's C tile in LDS
+#ifndef SD_F32_DMA_DEFAULT
+#define SD_F32_DMA_DEFAULT 1
+#endif
 static_assert(BM * LDC <= 2 * (BM + BN) * LDP, "C tile must fit in the operand stage");
 
 #ifdef SD_STAMP
 __device__ unsigned long long sd_c32_stamp_buf[8192 * 10];
 #endif
 
-// one 128x128 output tile
+#define SD_GLDS16_F32(gptr, lptr)                                                          \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),  \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// one 128x128 output tile.  DMA = true: the operand stage is written by LDS-DMA
+// (global_load_lds_dwordx4, no VGPR staging and no ds_write phase).  DMA rows are 128 bytes with no
+// padding (a wave instruction lands 8 rows = 1 KB contiguously), so the 16-byte chunk a lane FETCHES is
+// permuted at the source, chunk c of row r living at position c ^ ((r >> 1) & 7): the fragment reads of 16
+// consecutive rows then hit 16 different bank groups.
+template <bool DMA>
 __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int vec, const int tile_m, const int tile_n, float* smem) {
 #ifdef SD_STAMP
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-  float* As = smem;                 // [2][BM][LDP]
-  float* Bs = smem + 2 * BM * LDP;  // [2][BN][LDP]
+  constexpr int LDS_ROW = DMA ? BK : LDP;     // floats per staged row
+  float* As = smem;                           // [2][BM][LDS_ROW]
+  float* Bs = smem + 2 * BM * LDS_ROW;        // [2][BN][LDS_ROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -70,7 +83,7 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
     a_t[i] = m - seg;
     int n = n0 + r0 + 32 * i;
     n = n < p.cout ? n : p.cout - 1;
-    wptr[i] = W + (size_t)n * ktot + c4 * 4;
+    wptr[i] = W + (size_t)n * ktot + (DMA ? 0 : c4 * 4);
   }
   const int nk = p.taps * (p.cin_pad / BK);
   const int half = p.taps / 2;
@@ -90,6 +103,14 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
   f32x4 ra[4], rb[4];
   int ld_tap = 0, ld_c0 = 0;  // position of the next K step to fetch
   set_tap(0);
+  auto advance = [&]() {
+    ld_c0 += BK;
+    if (ld_c0 >= p.cin_pad) {
+      ld_c0 = 0;
+      ++ld_tap;
+      if (ld_tap < p.taps) set_tap(ld_tap);
+    }
+  };
   auto gload = [&]() {
     const int col = ld_c0 + c4 * 4;
     const int acol = col < p.cin ? col : 0;
@@ -99,12 +120,7 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
       rb[i] = *reinterpret_cast<const f32x4*>(wptr[i]);
       wptr[i] += BK;
     }
-    ld_c0 += BK;
-    if (ld_c0 >= p.cin_pad) {
-      ld_c0 = 0;
-      ++ld_tap;
-      if (ld_tap < p.taps) set_tap(ld_tap);
-    }
+    advance();
   };
   auto lstore = [&](int buf) {
     float* a = As + buf * BM * LDP;
@@ -114,6 +130,20 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
       *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDP + c4 * 4) = ra[i];
       *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDP + c4 * 4) = rb[i];
     }
+  };
+  // LDS-DMA of one K step into stage buf: this wave's instruction i lands rows 32 i + 8 wid .. + 7
+  // (lane = 8 (row & 7) + position); the lane fetches chunk  position ^ ((row >> 1) & 7)  of its row
+  const int gchunk = (c4 ^ ((r0 >> 1) & 7)) * 4;
+  auto gdma = [&](int buf) {
+    const int col = ld_c0 + gchunk;
+    const int acol = col < p.cin ? col : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      SD_GLDS16_F32(aptr[i] + acol, As + buf * BM * BK + (32 * i + 8 * wid) * BK);
+      SD_GLDS16_F32(wptr[i] + gchunk, Bs + buf * BN * BK + (32 * i + 8 * wid) * BK);
+      wptr[i] += BK;
+    }
+    advance();
   };
 
   f32x16 acc[2][2];
@@ -128,12 +158,17 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
   const int frag_k = (lane >> 5) * 4;
 
   struct Frag { f32x4 a0, a1, b0, b1; };
+  // DMA layout: logical chunk 2 k8 + (lane >> 5) of row r sits at position chunk ^ ((r >> 1) & 7)
+  int doff[4];
+#pragma unroll
+  for (int k8 = 0; k8 < 4; ++k8) doff[k8] = (((2 * k8 + (lane >> 5)) ^ ((frag_row >> 1) & 7)) * 4);
   auto fread = [&](const float* a, const float* b, int k8) {
     Frag f;
-    f.a0 = *reinterpret_cast<const f32x4*>(a + k8 * 8);
-    f.a1 = *reinterpret_cast<const f32x4*>(a + 32 * LDP + k8 * 8);
-    f.b0 = *reinterpret_cast<const f32x4*>(b + k8 * 8);
-    f.b1 = *reinterpret_cast<const f32x4*>(b + 32 * LDP + k8 * 8);
+    const int o = DMA ? doff[k8] : k8 * 8;
+    f.a0 = *reinterpret_cast<const f32x4*>(a + o);
+    f.a1 = *reinterpret_cast<const f32x4*>(a + 32 * LDS_ROW + o);
+    f.b0 = *reinterpret_cast<const f32x4*>(b + o);
+    f.b1 = *reinterpret_cast<const f32x4*>(b + 32 * LDS_ROW + o);
     return f;
   };
   auto mma = [&](const Frag& f) {
@@ -146,8 +181,13 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
     }
   };
 
-  gload();
-  lstore(0);
+  if (DMA) {
+    gdma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    gload();
+    lstore(0);
+  }
   __syncthreads();
 
   // One barrier per K step.  The fetch of step kt+1 is issued behind the first MFMA group
@@ -165,23 +205,27 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    const float* a = As + cur * BM * LDP + (wm * 64 + frag_row) * LDP + frag_k;
-    const float* b = Bs + cur * BN * LDP + (wn * 64 + frag_row) * LDP + frag_k;
+    const float* a = As + cur * BM * LDS_ROW + (wm * 64 + frag_row) * LDS_ROW + (DMA ? 0 : frag_k);
+    const float* b = Bs + cur * BN * LDS_ROW + (wn * 64 + frag_row) * LDS_ROW + (DMA ? 0 : frag_k);
     Frag f0 = fread(a, b, 0);
     Frag f1 = fread(a, b, 1);
     mma(f0);
     C32_TSEG(0);
-    if (more) gload();
+    if (more) {
+      if (DMA) gdma(cur ^ 1);      // the other stage is free since the barrier that ended step kt - 1
+      else gload();
+    }
     C32_TSEG(1);
     f0 = fread(a, b, 2);
     mma(f1);
     f1 = fread(a, b, 3);
     mma(f0);
     C32_TSEG(0);
-    if (more) lstore(cur ^ 1);
+    if (more && !DMA) lstore(cur ^ 1);
     C32_TSEG(2);
     mma(f1);
     C32_TSEG(0);
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
     __syncthreads();
     C32_TSEG(3);
     cur ^= 1;
@@ -242,12 +286,13 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
 // layers 13.6 -> 8.8 GB per launch (A alone is 1.7 GB; workgroups drift apart in K, so whole panels
 // would have to stay resident for more), throughput unchanged within the box-to-box noise (the
 // kernel is MFMA bound).  SD_TILE_ORDER=0 (host, diagnostic) keeps the launch order.
+template <bool DMA>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p, const int vec, const int order, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_tiles = (p.cout + BN - 1) / BN;
   if (order == 0) {
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-      conv_tile_f32(p, vec, t / n_tiles, t % n_tiles, smem);
+      conv_tile_f32<DMA>(p, vec, t / n_tiles, t % n_tiles, smem);
       __syncthreads();              // the next tile refills the LDS stage the epilogue was reading
     }
     return;
@@ -262,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
     const int band = wg / (8 * n_tiles);
     const int in_band = wg - band * 8 * n_tiles;
     const int rows = m_tiles - band * 8 < 8 ? m_tiles - band * 8 : 8;
-    conv_tile_f32(p, vec, band * 8 + in_band % rows, in_band / rows, smem);
+    conv_tile_f32<DMA>(p, vec, band * 8 + in_band % rows, in_band / rows, smem);
     __syncthreads();
   }
 }
@@ -383,10 +428,17 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
     SD_CHECK_LAUNCH("skinny_gemm_f32_kernel");
     return SD_OK;
   }
-  const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
+  // SD_F32_DMA=0|1 (diagnostic): operand staging through registers or by LDS-DMA
+  static const int dma = [] {
+    const char* e = getenv("SD_F32_DMA");
+    return e ? atoi(e) : SD_F32_DMA_DEFAULT;
+  }();
+  const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);   // the C tile of the epilogue needs BM * LDC <= this
   static bool attr_set = false;
   if (!attr_set) {
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel),
+    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -406,8 +458,12 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
                      2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
     const long ntiles = tiles_m * tiles_n;
     const long grid = (persist > 0 && ntiles > persist) ? persist : ntiles;
-    hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3((unsigned)grid), dim3(256), lds,
-                       static_cast<hipStream_t>(stream), *a, vec, order, (int)ntiles);
+    if (dma)
+      hipLaunchKernelGGL(conv_gemm_f32_kernel<true>, dim3((unsigned)grid), dim3(256), lds,
+                         static_cast<hipStream_t>(stream), *a, vec, order, (int)ntiles);
+    else
+      hipLaunchKernelGGL(conv_gemm_f32_kernel<false>, dim3((unsigned)grid), dim3(256), lds,
+                         static_cast<hipStream_t>(stream), *a, vec, order, (int)ntiles);
   }
   SD_CHECK_LAUNCH("conv_gemm_f32_kernel");
   return SD_OK;
