@@ -134,17 +134,18 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
   // LDS-DMA of one K step into stage buf: this wave's instruction i lands rows 32 i + 8 wid .. + 7
   // (lane = 8 (row & 7) + position); the lane fetches chunk  position ^ ((row >> 1) & 7)  of its row
   const int gchunk = (c4 ^ ((r0 >> 1) & 7)) * 4;
-  auto gdma = [&](int buf) {
+  auto gdma_part = [&](int buf, int i0, int i1) {
     const int col = ld_c0 + gchunk;
     const int acol = col < p.cin ? col : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = i0; i < i1; ++i) {
       SD_GLDS16_F32(aptr[i] + acol, As + buf * BM * BK + (32 * i + 8 * wid) * BK);
       SD_GLDS16_F32(wptr[i] + gchunk, Bs + buf * BN * BK + (32 * i + 8 * wid) * BK);
       wptr[i] += BK;
     }
-    advance();
+    if (i1 == 4) advance();
   };
+  auto gdma = [&](int buf) { gdma_part(buf, 0, 4); };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -207,19 +208,32 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
     const bool more = kt + 1 < nk;
     const float* a = As + cur * BM * LDS_ROW + (wm * 64 + frag_row) * LDS_ROW + (DMA ? 0 : frag_k);
     const float* b = Bs + cur * BN * LDS_ROW + (wn * 64 + frag_row) * LDS_ROW + (DMA ? 0 : frag_k);
+#ifndef SD_DMA_POS
+#define SD_DMA_POS 2   // measured: 0 (all at the start) 133.8, 1 (all after group 1) 133.3, 2 (halves after groups 1 and 2) 134.7, 3 (quarters) 129.8 TFLOP/s on 1024x1024
+#endif
+    if (DMA && more && SD_DMA_POS == 0) gdma(cur ^ 1);
+    if (DMA && more && SD_DMA_POS == 3) gdma_part(cur ^ 1, 0, 1);
     Frag f0 = fread(a, b, 0);
     Frag f1 = fread(a, b, 1);
     mma(f0);
     C32_TSEG(0);
     if (more) {
-      if (DMA) gdma(cur ^ 1);      // the other stage is free since the barrier that ended step kt - 1
-      else gload();
+      if (DMA) {                   // the other stage is free since the barrier that ended step kt - 1
+        if (SD_DMA_POS == 1) gdma(cur ^ 1);
+        if (SD_DMA_POS == 2) gdma_part(cur ^ 1, 0, 2);
+        if (SD_DMA_POS == 3) gdma_part(cur ^ 1, 1, 2);
+      } else {
+        gload();
+      }
     }
     C32_TSEG(1);
     f0 = fread(a, b, 2);
     mma(f1);
+    if (DMA && more && SD_DMA_POS == 2) gdma_part(cur ^ 1, 2, 4);
+    if (DMA && more && SD_DMA_POS == 3) gdma_part(cur ^ 1, 2, 3);
     f1 = fread(a, b, 3);
     mma(f0);
+    if (DMA && more && SD_DMA_POS == 3) gdma_part(cur ^ 1, 3, 4);
     C32_TSEG(0);
     if (more && !DMA) lstore(cur ^ 1);
     C32_TSEG(2);
