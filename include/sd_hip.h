@@ -142,6 +142,11 @@ typedef struct {
 
 int sd_conv1d_cl_f32(const sd_conv_args* args, sd_stream_t stream);
 int sd_conv1d_cl_f16(const sd_conv_args* args, sd_stream_t stream);
+/* Kernel-selection knobs (process-wide; for tests and measurements, results stay within f32 rounding).
+ * SD_TUNE_SKINNY_TILES: sd_conv1d_cl_f32 launches with fewer 128x128 tiles than `value` run the 32x32
+ * split-K kernel (default 128; 0 = always the 128x128 kernel; negative = restore the default). */
+#define SD_TUNE_SKINNY_TILES 1
+int sd_set_tuning(int key, long value);
 /* floats needed for sd_conv_args.colstat */
 size_t sd_colstat_floats(int M, int cout);
 /* colstat -> out [B][C] = mean (want_std = 0) or

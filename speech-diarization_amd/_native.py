@@ -18,6 +18,7 @@ SD_PAD_ZERO, SD_PAD_REFLECT = 0, 1
 SD_LOG_LN_EPS, SD_LOG_DB_TOPDB = 0, 1
 SD_ACT_NONE, SD_ACT_RELU, SD_ACT_TANH, SD_ACT_SIGMOID = 0, 1, 2, 3
 SD_DT_F32, SD_DT_F16 = 0, 1
+SD_TUNE_SKINNY_TILES = 1
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
 SD_ABI_VERSION = 3
@@ -104,6 +105,7 @@ PROTOTYPES = {
     "sd_fbank_f32": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_conv1d_cl_f32": (_I, [C.POINTER(sd_conv_args), _P]),
     "sd_conv1d_cl_f16": (_I, [C.POINTER(sd_conv_args), _P]),
+    "sd_set_tuning": (_I, [_I, C.c_long]),
     "sd_colstat_floats": (_Z, [_I, _I]),
     "sd_colstat_finish_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "sd_seg_mean_std_dt": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

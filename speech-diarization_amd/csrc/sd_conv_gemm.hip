@@ -17,6 +17,7 @@
 // Each lane reads FOUR consecutive k (one ds_read_b128) at k0 + 4h and feeds
 // element r to MFMA r, so MFMA r sums k in {k0 + r, k0 + 4 + r}; A and B use the
 // same permutation, and the sum over k is order independent up to rounding.
+#include <atomic>
 #include <cstdlib>
 
 #include "sd_common.h"
@@ -328,11 +329,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
 
 
 // ------------------------------------------------------------------------------------------
-// Per-segment layers (SE squeeze/excite, global-context bias, final FC): M = B rows only, so the
-// 128x128 kernel above would run on 8-16 workgroups.  Here a workgroup owns a 32x32 output tile
-// and its 4 waves split K four ways (exact-f32 32x32x2 MFMA, operands straight from global/L2 in
-// 16-byte pieces, same k-permutation as above); the four partial tiles are summed through LDS in
-// wave order, so the result does not depend on timing.
+// Launches with fewer 128x128 tiles than the chip has CUs: the per-segment layers (SE squeeze/excite,
+// global-context bias, final FC: M = B rows) and, at the reference's own batch sizes (16-128
+// segments), the narrow Res2Net convs (51 tiles at 32 segments: a 100 k-cycle tile on a fifth of the
+// CUs, 21 times per forward).  Here a workgroup owns a 32x32 output tile and its 4 waves split the
+// input channels four ways (every tap, a quarter of cin each; exact-f32 32x32x2 MFMA, operands
+// straight from global/L2 in 16-byte pieces, same k-permutation as above); the four partial tiles
+// are summed through LDS in wave order, so the result does not depend on timing.  Same operator
+// contract as the big kernel (taps with reflect padding, bias / activation / affine, tee).
 constexpr int SK_T = 32;
 constexpr int SK_LD = SK_T + 1;
 
@@ -345,22 +349,31 @@ __global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const sd_conv_args
   const int r = lane & 31, h = lane >> 5;
   int m = m0 + r; m = m < p.M ? m : p.M - 1;
   int n = n0 + r; n = n < p.cout ? n : p.cout - 1;
-  // this wave's K range: a quarter of cin_pad, a multiple of 8 (cin_pad % 32 == 0)
+  const int seg = (m / p.T) * p.T, t = m - seg;
+  // this wave's share of K: a quarter of cin_pad (a multiple of 8: cin_pad % 32 == 0) of every tap
   const int kq = p.cin_pad / 4;
   const int kb = wid * kq;
-  const float* xa = static_cast<const float*>(p.x) + (size_t)m * p.lda + p.a_col0 + 4 * h;
-  const float* wb = static_cast<const float*>(p.w) + (size_t)n * p.cin_pad + 4 * h;
+  const float* X = static_cast<const float*>(p.x) + p.a_col0 + 4 * h;
+  const float* wb = static_cast<const float*>(p.w) + (size_t)n * p.taps * p.cin_pad + 4 * h;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int half = p.taps / 2;
+  for (int tap = 0; tap < p.taps; ++tap) {
+    int tt = t + (tap - half) * p.dil;
+    tt = tt < 0 ? -tt : tt;
+    tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
+    const float* xa = X + (size_t)(seg + tt) * p.lda;
+    const float* wt = wb + (size_t)tap * p.cin_pad;
 #pragma unroll 4
-  for (int k = kb; k < kb + kq; k += 8) {
-    // columns past cin exist only in the zero-padded weights; do not read x there
-    const f32x4 a = (k + 4 * h < p.cin) ? *reinterpret_cast<const f32x4*>(xa + k) : z4;
-    const f32x4 b = *reinterpret_cast<const f32x4*>(wb + k);
+    for (int k = kb; k < kb + kq; k += 8) {
+      // columns past cin exist only in the zero-padded weights; do not read x there
+      const f32x4 a = (k + 4 * h < p.cin) ? *reinterpret_cast<const f32x4*>(xa + k) : z4;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(wt + k);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+    }
   }
   float* mine = red + wid * SK_T * SK_LD;
 #pragma unroll
@@ -371,6 +384,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const sd_conv_args
   const int mo = m0 + row;
   if (mo >= p.M) return;
   float* Y = static_cast<float*>(p.y);
+  float* TEE = static_cast<float*>(p.tee);
+  const float* TADD = static_cast<const float*>(p.tee_add);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int no = n0 + c0 + e;
@@ -383,6 +398,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const sd_conv_args
     v = v * (p.scale ? p.scale[no] : 1.f) + (p.shift ? p.shift[no] : 0.f);
     v = sd_apply_act(v, p.act2);
     Y[(size_t)mo * p.ldo + p.o_col0 + no] = v;
+    if (TEE && no >= p.tee_lo && no < p.tee_hi) {
+      if (TADD) v += TADD[(size_t)mo * p.ld_ta + p.ta_col0 + (no - p.tee_lo)];
+      TEE[(size_t)mo * p.ldt + (no - p.tee_lo)] = v;
+    }
   }
 }
 
@@ -395,6 +414,21 @@ extern "C" int sd_debug_read_c32_stamps(unsigned long long* out, int n) {
   return SD_OK;
 }
 #endif
+
+namespace {
+std::atomic<long> g_skinny_below{[] {
+  const char* e = getenv("SD_SKINNY_TILES");
+  return e ? atol(e) : 128L;     // measured at 16 / 32 / 64 / 128 segments: 128 beats 256 and 512
+}()};
+}  // namespace
+
+extern "C" int sd_set_tuning(int key, long value) {
+  if (key == SD_TUNE_SKINNY_TILES) {
+    g_skinny_below.store(value < 0 ? 128L : value, std::memory_order_relaxed);
+    return SD_OK;
+  }
+  return sd_set_error(SD_ERR_ARG, "sd_set_tuning: unknown key %d", key);
+}
 
 extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
   SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_f32: null args");
@@ -434,8 +468,9 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
   const long tiles_m = (a->M + BM - 1) / BM;
   const long tiles_n = (a->cout + BN - 1) / BN;
   SD_CHECK_ARG(tiles_m * tiles_n < (1L << 31), "sd_conv1d_cl_f32: grid too large");
-  // too few 128x128 tiles to fill the chip (per-segment layers): 32x32 tiles with in-workgroup split-K
-  if (a->T == 1 && a->taps == 1 && !a->tee && !a->colstat && tiles_m * tiles_n < 128) {
+  // fewer 128x128 tiles than half the CUs: 32x32 tiles with in-workgroup split-K (sd_set_tuning / SD_SKINNY_TILES)
+  const long skinny_below = g_skinny_below.load(std::memory_order_relaxed);
+  if (!a->colstat && tiles_m * tiles_n < skinny_below) {
     const long g = (long)((a->M + SK_T - 1) / SK_T) * ((a->cout + SK_T - 1) / SK_T);
     // (not counted in the SD_PROF_CONV_GEMM roofline figures: a different kernel, 0.2 % of the flops)
     hipLaunchKernelGGL(skinny_gemm_f32_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), *a);

@@ -22,7 +22,9 @@ def _small_sd(width=128):
 def test_config2_sharded_meeting_matches_unsharded_and_cpu(dev):
     """10 min, 8 voices: windows are embedded (a) in one piece, (b) as 8 round-robin shards that are
     gathered and de-interleaved (the W = 8 layout, executed rank by rank on this one GPU).  Rows are
-    independent in every kernel, so (b) must be BITWISE equal to (a); cluster labels must equal the CPU path's."""
+    independent in every kernel; the batch size only selects between kernels that sum K in a different order
+    (128x128 tiles vs the 32x32 split-K kernel of small launches), so (b) equals (a) to f32 rounding, the
+    same batch twice is BITWISE equal, and cluster labels equal the CPU path's."""
     from oracle.ecapa_ref import EcapaRef
     from oracle.pipeline_ref import encode_batch_ref
     from speech_diarization_amd import cluster, dist as sdist, ops, synth, vad
@@ -46,7 +48,10 @@ def test_config2_sharded_meeting_matches_unsharded_and_cpu(dev):
         idx = torch.from_numpy(sdist.shard_indices(n, r, W)).to(dev)
         gathered[r, : idx.numel()] = eng.embed(wav[idx])
     merged = sdist.deinterleave(gathered, n, W)
-    assert torch.equal(merged, whole)
+    cosd = 1.0 - torch.nn.functional.cosine_similarity(merged.double(), whole.double(), dim=1)
+    assert float(cosd.max()) < 1e-9 and float((merged - whole).abs().max()) < 1e-4 * float(whole.abs().max())
+    idx0 = torch.from_numpy(sdist.shard_indices(n, 0, W)).to(dev)
+    assert torch.equal(eng.embed(wav[idx0]), gathered[0, : idx0.numel()])       # run-to-run deterministic
     # clustering on the gathered embeddings vs the CPU path (subsampled: every 4th window keeps the CPU leg short)
     sub = np.arange(0, n, 4)
     e_gpu = whole[sub].cpu().numpy()

@@ -154,7 +154,8 @@ def test_epilogue_column_statistics(dev, wdt, B, T, cin, cout):
                       shift=shift.to(dev), colstat=cs)
     y_plain = ops.conv1d_cl(x.to(dev), ops.pack_weight(w, dev, wdt), T, cin=cin, bias=bias.to(dev), act="relu", scale=scale.to(dev),
                             shift=shift.to(dev))
-    assert torch.equal(y, y_plain)                                   # the stored output does not change
+    # the stored output does not change (to rounding: without colstat a launch this small takes the 32x32 split-K kernel)
+    assert (y.float() - y_plain.float()).abs().max() <= 2e-3 * y_plain.float().abs().max() * (1.0 if wdt == torch.float16 else 1e-3)
     assert bool(torch.isfinite(cs[:n_cs]).all()) and bool(torch.isnan(cs[n_cs:]).all())   # every tile wrote, nobody wrote past the end
     st = ops.colstat_finish(cs, y, B, T, pivot=shift.to(dev), want_std=True).cpu().double()
     mean_only = ops.colstat_finish(cs, y, B, T, pivot=shift.to(dev)).cpu().double()

@@ -65,8 +65,18 @@ def test_fbank_short_segments_and_errors(dev):
         fbank_device(torch.zeros(1600, device=dev), plan)
 
 
+@pytest.fixture(params=["auto", "tiles128"])
+def conv_kernel(request):
+    """"tiles128" pins the 128x128 f32 conv kernel; "auto" lets small launches take the 32x32 split-K kernel."""
+    from speech_diarization_amd import _native as N
+    lib = N.load()
+    N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, 0 if request.param == "tiles128" else -1), "sd_set_tuning")
+    yield request.param
+    N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, -1), "sd_set_tuning")
+
+
 @pytest.mark.parametrize("width,B,n", [(64, 6, 16000), (128, 3, 32000)])
-def test_ecapa_small_geometry_matches_oracle(dev, width, B, n):
+def test_ecapa_small_geometry_matches_oracle(dev, conv_kernel, width, B, n):
     from oracle import ecapa_ref, fbank_ref
     from speech_diarization_amd import synth
     from speech_diarization_amd.engine import EmbeddingEngine
@@ -81,7 +91,7 @@ def test_ecapa_small_geometry_matches_oracle(dev, width, B, n):
     assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max()
 
 
-def test_ecapa_full_geometry_matches_oracle(dev):
+def test_ecapa_full_geometry_matches_oracle(dev, conv_kernel):
     """The spkrec-ecapa geometry (C=1024, 20.8 M parameters) on 2 s segments."""
     from oracle import pipeline_ref
     from speech_diarization_amd import synth

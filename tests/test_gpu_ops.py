@@ -24,6 +24,17 @@ def _ref_conv_cl(x, w, b, T, dil):
     return y.transpose(1, 2).reshape(M, -1)
 
 
+@pytest.fixture(params=["auto", "tiles128"])
+def conv_kernel(request):
+    """Small launches pick the 32x32 split-K kernel by themselves; "tiles128" pins the 128x128 kernel so that
+    both implementations of the operator see every case."""
+    from speech_diarization_amd import _native as N
+    lib = N.load()
+    N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, 0 if request.param == "tiles128" else -1), "sd_set_tuning")
+    yield request.param
+    N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, -1), "sd_set_tuning")
+
+
 @pytest.mark.parametrize("B,T,cin,cout,k,dil", [
     (3, 201, 1024, 1024, 1, 1),     # pointwise, tile-aligned N
     (5, 101, 128, 128, 3, 3),       # Res2Net conv, M not a tile multiple, segments straddle tiles
@@ -31,7 +42,7 @@ def _ref_conv_cl(x, w, b, T, dil):
     (7, 1, 1024, 128, 1, 1),        # SE squeeze: T = 1, tiny M
     (4, 33, 256, 192, 1, 1),        # cout not a multiple of the N tile
 ])
-def test_conv1d_cl_matches_torch(dev, B, T, cin, cout, k, dil):
+def test_conv1d_cl_matches_torch(dev, conv_kernel, B, T, cin, cout, k, dil):
     from speech_diarization_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + T)
     x = torch.randn(B * T, cin, generator=g, dtype=torch.float64)
@@ -47,7 +58,7 @@ def test_conv1d_cl_matches_torch(dev, B, T, cin, cout, k, dil):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
-def test_conv1d_cl_slices_tee_and_per_segment_bias(dev):
+def test_conv1d_cl_slices_tee_and_per_segment_bias(dev, conv_kernel):
     from speech_diarization_amd import ops
     g = torch.Generator().manual_seed(5)
     B, T, C, hid = 3, 57, 256, 32
