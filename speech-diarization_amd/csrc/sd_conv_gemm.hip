@@ -209,20 +209,15 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
     const bool more = kt + 1 < nk;
     const float* a = As + cur * BM * LDS_ROW + (wm * 64 + frag_row) * LDS_ROW + (DMA ? 0 : frag_k);
     const float* b = Bs + cur * BN * LDS_ROW + (wn * 64 + frag_row) * LDS_ROW + (DMA ? 0 : frag_k);
-#ifndef SD_DMA_POS
-#define SD_DMA_POS 2   // measured: 0 (all at the start) 133.8, 1 (all after group 1) 133.3, 2 (halves after groups 1 and 2) 134.7, 3 (quarters) 129.8 TFLOP/s on 1024x1024
-#endif
-    if (DMA && more && SD_DMA_POS == 0) gdma(cur ^ 1);
-    if (DMA && more && SD_DMA_POS == 3) gdma_part(cur ^ 1, 0, 1);
+    // DMA pieces go out in two halves, behind the first and the second MFMA group (measured on 1024x1024:
+    // all at the start of the step 133.8, all behind group 1 133.3, halves 134.7, quarters 129.8 TFLOP/s)
     Frag f0 = fread(a, b, 0);
     Frag f1 = fread(a, b, 1);
     mma(f0);
     C32_TSEG(0);
     if (more) {
       if (DMA) {                   // the other stage is free since the barrier that ended step kt - 1
-        if (SD_DMA_POS == 1) gdma(cur ^ 1);
-        if (SD_DMA_POS == 2) gdma_part(cur ^ 1, 0, 2);
-        if (SD_DMA_POS == 3) gdma_part(cur ^ 1, 1, 2);
+        gdma_part(cur ^ 1, 0, 2);
       } else {
         gload();
       }
@@ -230,11 +225,9 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
     C32_TSEG(1);
     f0 = fread(a, b, 2);
     mma(f1);
-    if (DMA && more && SD_DMA_POS == 2) gdma_part(cur ^ 1, 2, 4);
-    if (DMA && more && SD_DMA_POS == 3) gdma_part(cur ^ 1, 2, 3);
+    if (DMA && more) gdma_part(cur ^ 1, 2, 4);
     f1 = fread(a, b, 3);
     mma(f0);
-    if (DMA && more && SD_DMA_POS == 3) gdma_part(cur ^ 1, 3, 4);
     C32_TSEG(0);
     if (more && !DMA) lstore(cur ^ 1);
     C32_TSEG(2);
