@@ -226,9 +226,9 @@ __device__ unsigned long long sd_stamp_buf[8192 * 8];
 // ------------------------------------------------------------------------------------------
 // 256x256 tile for the large square convs, fed by LDS-DMA (global_load_lds_dwordx4 writes the operand
 // tiles straight into an LDS ring, no VGPR staging).  What paces every f16 variant is the CU's
-// vector-memory path (~17 B/clk = 41 GB/s per CU of operand ingest, measured with in-kernel cycle
-// counters: tools/stamp_t256.py), so the lever is bytes per flop, and this tile has half those of the
-// 128x128 kernel above.  (A 256x128 LDS-DMA variant and a ninth "L2 prefetch" wave were tried and
+// vector-memory path: a 1 KB DMA piece takes ~57 cycles of it, i.e. ~18 B/clk per CU of operand ingest
+// (in-kernel cycle counters, tools/stamp_t256.py: a K step is 1789 cycles for 32 KB and 1024 cycles of
+// MFMA), so the lever is bytes per flop, and this tile has half those of the 128x128 kernel above.  (A 256x128 LDS-DMA variant and a ninth "L2 prefetch" wave were tried and
 // dropped: 800 vs 864 TFLOP/s on 3072x3072, and slower, respectively.)  8 waves as 2 (M) x 4 (N), each
 // 128x64 = 4x2 MFMA tiles (128 accumulator registers); K step 32 halfs, i.e. 64-byte LDS rows,
 // [512 rows] = 32 KB per stage, a 4-stage LDS-DMA ring (three K steps in flight), counted vmcnt
@@ -371,9 +371,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
     SD_TSEG(0);
     __builtin_amdgcn_s_barrier();
     SD_TSEG(1);
-    // SIMD partners (waves w and w+4) are staggered: the first half issues its DMA pieces right after
-    // the barrier, the second half only after its first MFMA group, so one partner's ~100-cycle-per-piece
-    // DMA issue runs under the other's MFMAs instead of all eight waves issuing, then all computing
     // SIMD partners (waves w and w+4) are staggered: the first half issues its DMA pieces right after
     // the barrier, the second half after its first MFMA group, so one partner's DMA issue (~100 cycles
     // per piece: the CU's vector-memory path, not the instruction count, paces it) runs under the
