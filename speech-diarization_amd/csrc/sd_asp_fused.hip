@@ -208,9 +208,12 @@ int launch_f16(const void* a1, const void* wc, const void* h, int ldh, int B, in
 // waves), fetched for the next group while the softmax of this one runs; h for the group is
 // fetched while its MFMAs run.  Same k-permutation
 // as the conv kernel: a lane reads 4 consecutive k with one 16-byte access and feeds 4 MFMAs.
-// Measured at 5000 segments: 8.05 ms against 14.2 ms for the conv + pooling pair; matrix pipe 66 % busy
-// (the softmax VALU phase of a wave does not hide under its SIMD partner's MFMAs; delaying one of
-// the two by 4-10 k cycles changes nothing).
+// Measured at 5000 segments: 8.05 ms against 14.2 ms for the conv + pooling pair; matrix pipe 66 % busy.
+// In-kernel cycle counters, per group and wave: 5.7 k cycles issuing the scattered h / weight loads (16
+// lines per instruction), 14.5 k in the MFMA loop (13.3 k of MFMA), 12 k in softmax + store: a wave is in
+// its MFMA loop 45 % of the time and two per SIMD do not interleave perfectly.  Tried and dropped: delaying
+// one partner by 4-10 k cycles (no change), s_setprio around the MFMA loop (-0.7 %), three waves per SIMD
+// (12-wave workgroups; 168 registers mean spills and no h prefetch: 8.5 ms).
 constexpr int FLD = AK + 4;   // LDS row stride of the f32 a1 tile in floats (528 B: conflict-free ds_read_b128)
 
 template <int NT>   // 16-frame tiles: T <= 16 * NT
