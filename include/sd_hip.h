@@ -14,7 +14,11 @@
  *   sd_ecapa_*            replaces  speechbrain ECAPA_TDNN forward inside
  *                                   EncoderClassifier.encode_batch
  *                                   [REF speech_encode.py:73-78] [REF ecapa_annote.py:22]
- *   sd_conv1d_cl_f32 ...  the layer operators sd_ecapa_forward is built from
+ *   sd_conv1d_cl_f32 / _f16, sd_seg_mean_std_*, sd_se_scale_residual_*, sd_asp_pool_*,
+ *   sd_asp_attend_pool_dt, sd_colstat_finish_dt
+ *                         the layer operators sd_ecapa_forward is built from: speechbrain's Conv1d /
+ *                         TDNNBlock / SEBlock / AttentiveStatisticsPooling as reached from the same
+ *                         encode_batch call [REF speech_encode.py:77]
  *   sd_cosine_affinity_f32 replaces sklearn cosine_similarity(X)
  *                                   [REF anti_stick_diarize.py:177] [REF diar_diag.py:215,219,278,355]
  *   sd_l2norm_rows_f32    replaces  X / (||X|| + 1e-8) [REF anti_stick_diarize.py:176,430]
