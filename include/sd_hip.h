@@ -259,6 +259,12 @@ int sd_cosine_affinity_f32(const float* x, int N, int D, float* out, int ldo,
  * computes when the affinity is row-block sharded (same workspace size). */
 int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row_lo, int row_hi, float* out, int ldo,
                                 void* ws_dev, size_t ws_bytes, sd_stream_t stream);
+/* The same rows with f16 matrix-core throughput and f32-level accuracy (|error| ~ 3e-7): the normalised rows
+ * are split x = hi + lo (two f16 matrices) and hi.hi + hi.lo + lo.hi runs as one f16 GEMM with f32
+ * accumulation.  For the large affinities of BASELINE configs[4]; same semantics as the _f32 entry. */
+size_t sd_cosine_split16_workspace_bytes(int N, int D);
+int sd_cosine_affinity_rows_split16(const float* x, int N, int D, int row_lo, int row_hi, float* out, int ldo,
+                                    void* ws_dev, size_t ws_bytes, sd_stream_t stream);
 /* sims[i] = <x[i], x[i+1]> / (||x[i]|| * ||x[i+1]|| + eps), i < N-1 */
 int sd_adjacent_cosine_f32(const float* x, int ldx, int N, int D, float eps, float* sims, sd_stream_t stream);
 /* best[i] = argmax_k <w[i], c[k]> (first max wins, numpy argmax), score[i] = max */

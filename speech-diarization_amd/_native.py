@@ -124,6 +124,8 @@ PROTOTYPES = {
     "sd_cosine_workspace_bytes": (_Z, [_I, _I]),
     "sd_cosine_affinity_f32": (_I, [_P, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_cosine_affinity_rows_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    "sd_cosine_split16_workspace_bytes": (_Z, [_I, _I]),
+    "sd_cosine_affinity_rows_split16": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_adjacent_cosine_f32": (_I, [_P, _I, _I, _I, _F, _P, _P]),
     "sd_sim_argmax_f32": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
 }

@@ -126,3 +126,48 @@ extern "C" int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row
   a.act = SD_ACT_NONE; a.act2 = SD_ACT_NONE;
   return sd_conv1d_cl_f32(&a, stream);
 }
+
+// The same matrix at the f16 matrix-core rate with f32-level accuracy (BASELINE configs[4]: the 50k x 50k
+// affinity): normalised rows are split  x = hi + lo  into two f16 operand matrices (sd_pool.hip,
+// split16_rows_kernel) and  hi.hi + hi.lo + lo.hi  is ONE f16 GEMM over K = 3 * D with f32 accumulation,
+// run by the conv operator's 256x256 LDS-DMA kernel; the result is then bound by writing 4 N^2 bytes.
+static int pad64(int d) { return (d + 63) & ~63; }
+
+
+extern "C" size_t sd_cosine_split16_workspace_bytes(int N, int D) {
+  if (N <= 0 || D <= 0) return 0;
+  const size_t f32 = ((size_t)N * pad32(D) * sizeof(float) + 255) & ~(size_t)255;
+  const size_t h = ((size_t)N * 3 * pad64(D) * 2 + 255) & ~(size_t)255;
+  return f32 + 2 * h;
+}
+
+extern "C" int sd_cosine_affinity_rows_split16(const float* x, int N, int D, int row_lo, int row_hi, float* out, int ldo,
+                                               void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
+  SD_CHECK_ARG(N >= 0 && D > 0, "sd_cosine_affinity_rows_split16: N=%d D=%d", N, D);
+  SD_CHECK_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= N, "sd_cosine_affinity_rows_split16: bad row block [%d,%d) of %d", row_lo, row_hi, N);
+  if (N == 0 || row_lo == row_hi) return SD_OK;
+  SD_CHECK_ARG(x && out && ws_dev, "sd_cosine_affinity_rows_split16: null pointer");
+  SD_CHECK_ARG(ldo >= N, "sd_cosine_affinity_rows_split16: ldo=%d < N=%d", ldo, N);
+  if (ws_bytes < sd_cosine_split16_workspace_bytes(N, D))
+    return sd_set_error(SD_ERR_WORKSPACE, "sd_cosine_affinity_rows_split16: workspace %zu < %zu bytes", ws_bytes,
+                        sd_cosine_split16_workspace_bytes(N, D));
+  const int Dp = pad32(D), Dk = pad64(D);
+  char* ws = static_cast<char*>(ws_dev);
+  float* xn = reinterpret_cast<float*>(ws);
+  const size_t f32 = ((size_t)N * Dp * sizeof(float) + 255) & ~(size_t)255;
+  const size_t h = ((size_t)N * 3 * Dk * 2 + 255) & ~(size_t)255;
+  void* A = ws + f32;
+  void* B = ws + f32 + h;
+  int e = sd_l2norm_rows_f32(x, D, N, D, 0.f, 1, xn, Dp, stream);
+  if (e != SD_OK) return e;
+  e = sd_split16_rows(xn, Dp, N, D, Dk, A, B, stream);
+  if (e != SD_OK) return e;
+  sd_conv_args a = {};
+  a.x = static_cast<char*>(A) + (size_t)row_lo * 3 * Dk * 2; a.lda = 3 * Dk; a.a_col0 = 0; a.x_dtype = SD_DT_F16;
+  a.w = B; a.w_dtype = SD_DT_F16;
+  a.y = out; a.ldo = ldo; a.o_col0 = 0; a.y_dtype = SD_DT_F32;
+  a.M = row_hi - row_lo; a.T = 1;
+  a.cin = 3 * Dk; a.cin_pad = 3 * Dk; a.cout = N; a.taps = 1; a.dil = 1;
+  a.act = SD_ACT_NONE; a.act2 = SD_ACT_NONE;
+  return sd_conv1d_cl_f16(&a, stream);
+}

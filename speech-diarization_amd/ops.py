@@ -179,9 +179,11 @@ def l2norm_rows(x: torch.Tensor, eps_add: float = 0.0, sklearn_zero_guard: bool 
     return out
 
 
-def cosine_affinity(x: torch.Tensor, out: torch.Tensor | None = None, rows: tuple[int, int] | None = None) -> torch.Tensor:
+def cosine_affinity(x: torch.Tensor, out: torch.Tensor | None = None, rows: tuple[int, int] | None = None,
+                    split16: bool = False) -> torch.Tensor:
     """sklearn `cosine_similarity(X)` semantics on the GPU: f32 [N, D] -> f32 [N, N]
-    (or rows [lo, hi) of it -> [hi-lo, N] when `rows` is given)."""
+    (or rows [lo, hi) of it -> [hi-lo, N] when `rows` is given).  `split16`: same result to ~3e-7 through
+    the f16 matrix cores (rows split hi + lo), for very large N."""
     _need_cuda(x)
     lib = N.load()
     x = x.contiguous().float()
@@ -192,10 +194,11 @@ def cosine_affinity(x: torch.Tensor, out: torch.Tensor | None = None, rows: tupl
     if n == 0 or hi == lo:
         return out
     with torch.cuda.device(x.device):
-        ws_bytes = int(lib.sd_cosine_workspace_bytes(n, d))
+        size_fn, fn, name = ((lib.sd_cosine_split16_workspace_bytes, lib.sd_cosine_affinity_rows_split16, "sd_cosine_affinity_rows_split16")
+                             if split16 else (lib.sd_cosine_workspace_bytes, lib.sd_cosine_affinity_rows_f32, "sd_cosine_affinity_rows_f32"))
+        ws_bytes = int(size_fn(n, d))
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-        N.check(lib.sd_cosine_affinity_rows_f32(x.data_ptr(), n, d, lo, hi, out.data_ptr(), out.stride(0), ws.data_ptr(), ws_bytes,
-                                                _stream(x)), "sd_cosine_affinity_rows_f32")
+        N.check(fn(x.data_ptr(), n, d, lo, hi, out.data_ptr(), out.stride(0), ws.data_ptr(), ws_bytes, _stream(x)), name)
     return out
 
 

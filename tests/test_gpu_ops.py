@@ -155,6 +155,24 @@ def test_cosine_affinity_matches_sklearn(dev, n, d):
         assert abs(got[4, 5] - 1.0) < 1e-6
 
 
+@pytest.mark.parametrize("n,d", [(300, 192), (1500, 192), (129, 50), (2048, 192)])
+def test_cosine_affinity_split16_matches_sklearn(dev, n, d):
+    """hi + lo split through the f16 matrix cores: same bar as the exact-f32 kernel."""
+    from sklearn.metrics.pairwise import cosine_similarity
+    from speech_diarization_amd import ops
+    rng = np.random.default_rng(n + d)
+    x = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.01, 30.0, size=(n, 1)).astype(np.float32)
+    x[7] = 0.0
+    ref = cosine_similarity(x.astype(np.float64))
+    xd = torch.from_numpy(x).to(dev)
+    got = ops.cosine_affinity(xd, split16=True).cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-6
+    assert np.all(got[7] == 0.0) and np.all(got[:, 7] == 0.0)
+    lo, hi = n // 3, n // 3 + 37
+    blk = ops.cosine_affinity(xd, rows=(lo, hi), split16=True).cpu().numpy()
+    assert np.abs(blk - ref[lo:hi]).max() < 2e-6
+
+
 def test_cosine_affinity_identity_and_empty(dev):
     from speech_diarization_amd import ops
     eye = torch.eye(192, device=dev)

@@ -95,6 +95,16 @@ def main():
     out["micro_batch_sweep"] = {p: micro_batch_sweep(sd, dev, p) for p in ("f32", "f16")}
     out["host_api_numpy_in_out_f32"] = [host_api_rate(b) for b in (32, 128)]
     out["affinity_50k"] = {"ms": dt * 1e3, "tflops": 384.0 * 50000 ** 2 / dt / 1e12, "write_tb_s": 4.0 * 50000 ** 2 / dt / 1e12}
+    ops.cosine_affinity(x, out=K, split16=True)
+    torch.cuda.synchronize()
+    t = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ops.cosine_affinity(x, out=K, split16=True)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter() - t0)
+    dt = min(t)
+    out["affinity_50k_split16"] = {"ms": dt * 1e3, "f16_tflops": 3 * 384.0 * 50000 ** 2 / dt / 1e12, "write_tb_s": 4.0 * 50000 ** 2 / dt / 1e12}
     print(json.dumps(out))
 
 
