@@ -177,7 +177,8 @@ def main():
         c16_tf = c16_flops / (c16_ms * 1e-3) / 1e12 if c16_ms > 0 else 0.0
         extra_f16 = {
             "note": "same step with f16 operands / f32 accumulation on the frame-level convs and f16 activations "
-                    "(BASELINE.json configs[4]); NOT the headline value",
+                    "(BASELINE.json configs[4]); operand mantissa = TF32's 10 bits, which the reference enables for its own "
+                    "CUDA matmuls/convs [REF diarization_baseline.py:20-21]; NOT the headline value",
             "value": n_total * args.steps / dt16, "unit": "segments/s", "ms_per_step": dt16 / args.steps * 1e3, "dtype": "f16",
             "max_cosine_distance_vs_f32_path": float(cosd.max().item()),
             "roofline": {"kernel": "conv_gemm_f16_kernel", "bound": "mfma", "achieved": c16_tf, "peak": F16_MFMA_PEAK_TFLOPS,
