@@ -19,6 +19,49 @@ def _small_sd(width=128):
     return synth.make_ecapa_state_dict(1234, synth.EcapaConfig.small(width))
 
 
+def test_config1_full_size_properties(dev):
+    """BASELINE configs[1] at full size (10 000 synthetic 2 s segments, full spkrec-ecapa geometry, micro-batch
+    5000): properties that need no oracle at this size, plus the float64 oracle on a handful of rows.
+    Rows are independent: a permuted batch gives the permuted embeddings and a small batch (other kernels) the
+    same ones, both to f32 rounding; the same batch twice is bitwise equal; the f16 path stays inside the 1e-3
+    cosine bar."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import ops, synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    n = 10000
+    g = torch.Generator(device=dev).manual_seed(11)
+    wav = (torch.randn((n, 32000), generator=g, device=dev) * 0.1).clamp_(-1.0, 1.0)
+    wav[77] = 0.0                                            # a silent segment must not poison its neighbours
+    eng = EmbeddingEngine(sd, dev, max_batch=5000)
+    emb = eng.embed(wav)
+    assert emb.shape == (n, 192) and bool(torch.isfinite(emb).all())
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(3)).to(dev)
+    emb_p = eng.embed(wav[perm])
+    # not bitwise: the SE / global statistics are summed per 128-row tile, so a segment's partial sums are
+    # grouped by where it sits in the batch (f32 rounding of a 201-term mean)
+    cosp = 1.0 - torch.nn.functional.cosine_similarity(emb_p.double(), emb[perm].double(), dim=1)
+    assert float(cosp.max()) < 1e-10 and float((emb_p - emb[perm]).abs().max()) < 1e-5 * float(emb.abs().max())
+    assert torch.equal(eng.embed(wav), emb)                  # run-to-run deterministic
+    idx = torch.tensor([0, 77, 4999, 5000, 9999], device=dev)
+    small = eng.embed(wav[idx])                              # 5 segments: the small-launch kernels
+    cosd = 1.0 - torch.nn.functional.cosine_similarity(small.double(), emb[idx].double(), dim=1)
+    assert float(cosd.max()) < 1e-9
+    ref = pipeline_ref.encode_batch_ref(sd, wav[idx].cpu().numpy(), torch.float64)
+    e = emb[idx].cpu().numpy().astype(np.float64)
+    cd = 1.0 - (e * ref).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(ref, axis=1))
+    assert cd.max() < 1e-5, cd
+    K = ops.cosine_affinity(emb)
+    assert (torch.diagonal(K) - 1.0).abs().max() < 1e-5 and float(K.abs().max()) <= 1.0 + 1e-5
+    assert (K - K.T).abs().max() < 2e-7
+    del eng, K
+    torch.cuda.empty_cache()
+    e16 = EmbeddingEngine(sd, dev, max_batch=5000, precision="f16").embed(wav)
+    cos16 = 1.0 - torch.nn.functional.cosine_similarity(e16.double(), emb.double(), dim=1)
+    assert float(cos16.max()) < 1e-3
+    print(f"config 1 full size: f16 vs f32 max cosine distance {float(cos16.max()):.2e}, vs float64 oracle {cd.max():.2e}")
+
+
 def test_config2_sharded_meeting_matches_unsharded_and_cpu(dev):
     """10 min, 8 voices: windows are embedded (a) in one piece, (b) as 8 round-robin shards that are
     gathered and de-interleaved (the W = 8 layout, executed rank by rank on this one GPU).  Rows are
