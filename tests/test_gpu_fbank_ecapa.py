@@ -49,6 +49,33 @@ def test_fbank_known_answers(dev):
     assert abs(int(np.argmax(f[50])) - expect) <= 1
 
 
+@pytest.mark.parametrize("kind", ["torchaudio", "speechbrain"])
+def test_fbank_full_size_properties(dev, kind):
+    """10 000 segments of 2 s (BASELINE configs[1] size): finite, per-utterance mean removed, rows independent
+    (duplicates planted far apart come out bitwise equal), gain behaves as the front end says (ln: a gain g adds
+    2 ln g before mean removal, i.e. nothing after it where x >> eps; dB with top_db: invariant), and a strided
+    sample of rows matches the float64 oracle."""
+    from oracle import fbank_ref
+    from speech_diarization_amd.engine import fbank_device
+    from speech_diarization_amd.features import FbankPlan
+    plan = FbankPlan(kind)
+    n = 10000
+    g = torch.Generator(device=dev).manual_seed(5)
+    wav = (torch.randn((n, 32000), generator=g, device=dev) * 0.1).clamp_(-1.0, 1.0)
+    wav[9000] = wav[3]
+    wav[4321] = 0.5 * wav[10]
+    f = fbank_device(wav, plan, mean_norm=True)
+    assert f.shape == (n, 201, 80) and bool(torch.isfinite(f).all())
+    assert float(f.mean(dim=1).abs().max()) < 2e-5
+    assert torch.equal(f[9000], f[3])
+    assert float((f[4321] - f[10]).abs().max()) < 2e-2          # ln(x + 1e-6): exact only where x >> eps
+    idx = [0, 3, 2500, 4321, 9999]
+    ref_fn = fbank_ref.fbank_batch_ref if kind == "torchaudio" else fbank_ref.speechbrain_fbank_ref
+    ref = ref_fn(wav[idx].cpu().numpy().astype(np.float64))
+    tol = 5e-4 if kind == "torchaudio" else 2e-3          # ln vs dB units
+    assert np.abs(f[idx].cpu().numpy() - ref).max() < tol
+
+
 def test_fbank_short_segments_and_errors(dev):
     from oracle import fbank_ref
     from speech_diarization_amd import synth, _native
