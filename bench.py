@@ -183,7 +183,10 @@ def main():
             "max_cosine_distance_vs_f32_path": float(cosd.max().item()),
             "roofline": {"kernel": "conv_gemm_f16_kernel", "bound": "mfma", "achieved": c16_tf, "peak": F16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": c16_tf / F16_MFMA_PEAK_TFLOPS, "launches": c16_n,
-                         "avg_launch_ms": c16_ms / max(c16_n, 1), "share_of_step_time": c16_ms * 1e-3 / dt16},
+                         "avg_launch_ms": c16_ms / max(c16_n, 1), "share_of_step_time": c16_ms * 1e-3 / dt16,
+                         # rocprofv3 --pmc pass of `bench.py --precision f16` (profiles/mfma_util_f16.json), not live
+                         "mfma_util_pmc": {k: (v or {}).get("mfma_util") for k, v in load_profile_json("mfma_util_f16.json").items()
+                                           if k.startswith("conv_gemm_f16")}},
         }
 
     if rank == 0:
