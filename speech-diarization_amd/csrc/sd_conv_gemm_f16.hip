@@ -237,15 +237,26 @@ __device__ unsigned long long sd_stamp_buf[8192 * 8];
 // The 256x256 f32 C tile does not fit LDS: the epilogue runs once per 128-row half.
 constexpr int TBM = 256;
 constexpr int TBN = 256;
-constexpr int TBK = 32;                            // halfs
-constexpr int TROW = TBK * 2;                      // 64 bytes
-constexpr int TSTAGE = (TBM + TBN) * TROW;         // 32768
-constexpr int TNST = 4;
-constexpr int TLDS_BYTES = TNST * TSTAGE;          // 131072
+#ifndef SD_T256_K_DEFAULT
+#define SD_T256_K_DEFAULT 64
+#endif
+constexpr int TLDS_BYTES = 131072;                 // the operand ring: 4 stages of K = 32 or 2 stages of K = 64
 static_assert((TBM / 2) * TBN * 4 <= TLDS_BYTES, "half C tile must fit in the ring");
+// TBK = 64 (128-byte rows): a DMA piece lands 8 rows and reads 8 FULL 128-byte cache lines.  With TBK = 32 a
+// piece reads half of 16 lines, and the other halves are fetched again one K step later: the L1 / vector-memory
+// path then moves twice the lines per useful byte (tools/micro/dma_rate.hip: whole lines stream at 76 B/clk/CU
+// from L2; the TBK = 32 loop was held at 18 B/clk).
 
-template <typename TO>
+template <typename TO, int TBK>
 __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec) {
+  constexpr int TROW = TBK * 2;                      // bytes per staged row: 64 or 128
+  constexpr int SLOTS = TROW / 16;                   // 16-byte slots per row: 4 or 8
+  constexpr int SWSH = TROW == 64 ? 2 : 1;           // rows per 256-byte bank row = 1 << SWSH
+  constexpr int TSTAGE = (TBM + TBN) * TROW;         // 32 KB or 64 KB
+  constexpr int TNST = TLDS_BYTES / TSTAGE;          // 4 or 2
+  constexpr int RPI = 1024 / TROW;                   // rows one wave instruction lands: 16 or 8
+  constexpr int RSTEP = 512 / SLOTS;                 // rows covered by the 512 threads per piece: 128 or 64
+  constexpr int NR = TBM / RSTEP;                    // pieces per operand per K step and thread: 2 or 4
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -263,19 +274,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   const int tile_m = wg / n_tiles;
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
-  // staging role: thread (r0 = tid >> 2, ps = tid & 3) fills physical slot ps of A rows r0, r0+128 and of
-  // B rows r0, r0+128; one wave-instruction writes 16 whole rows (1 KB) of LDS
-  const int r0 = tid >> 2;
-  const int ps = tid & 3;
-  int a_seg[2], a_t[2], a_ls[2];
-  const _Float16* aptr[2];
-  const _Float16* wptr[2];
+  // staging role: thread (r0 = tid / SLOTS, ps = tid % SLOTS) fills physical slot ps of A rows r0 + RSTEP i and
+  // of the same B rows; one wave-instruction writes RPI whole rows (1 KB) of LDS
+  const int r0 = tid / SLOTS;
+  const int ps = tid % SLOTS;
+  int a_seg[NR], a_t[NR], a_ls[NR];
+  const _Float16* aptr[NR];
+  const _Float16* wptr[NR];
   const int ktot = p.taps * p.cin_pad;
   const _Float16* W = static_cast<const _Float16*>(p.w);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = r0 + 128 * i;
-    const int ls = (ps ^ ((row >> 2) & 3)) * 8;    // logical k offset (halfs) that belongs in this lane's slot
+  for (int i = 0; i < NR; ++i) {
+    const int row = r0 + RSTEP * i;
+    const int ls = (ps ^ ((row >> SWSH) & (SLOTS - 1))) * 8;    // logical k offset (halfs) that belongs in this lane's slot
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
     const int seg = (m / p.T) * p.T;
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   auto set_tap = [&](int tap) {
     const int delta = (tap - half) * p.dil;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NR; ++i) {
       int tt = a_t[i] + delta;
       tt = tt < 0 ? -tt : tt;
       tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
@@ -301,20 +312,20 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   };
   int ld_tap = 0, ld_c0 = 0;
   set_tap(0);
-  const int dst_a = (wid * 16) * TROW;                  // + 128*i rows
-  const int dst_b = TBM * TROW + (wid * 16) * TROW;
-  // DMA piece g of a K step: g = 0, 1 -> A rows r0, r0 + 128; g = 2, 3 -> B rows r0, r0 + 128
+  const int dst_a = (wid * RPI) * TROW;                 // + RSTEP * i rows
+  const int dst_b = TBM * TROW + (wid * RPI) * TROW;
+  // DMA piece g of a K step: g < NR -> A rows r0 + RSTEP g; else B rows r0 + RSTEP (g - NR)
   auto piece = [&](char* base, int g) {
-    if (g < 2) {
+    if (g < NR) {
       const int col = ld_c0 + a_ls[g];
-      SD_GLDS16(aptr[g] + (col < p.cin ? col : 0), base + dst_a + g * 128 * TROW);
+      SD_GLDS16(aptr[g] + (col < p.cin ? col : 0), base + dst_a + g * RSTEP * TROW);
     } else {
-      SD_GLDS16(wptr[g - 2], base + dst_b + (g - 2) * 128 * TROW);
+      SD_GLDS16(wptr[g - NR], base + dst_b + (g - NR) * RSTEP * TROW);
     }
   };
   auto advance = [&]() {
-    wptr[0] += TBK;
-    wptr[1] += TBK;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) wptr[i] += TBK;
     ld_c0 += TBK;
     if (ld_c0 >= p.cin_pad) {
       ld_c0 = 0;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   auto issue = [&](int stage) {
     char* base = smem_raw + stage * TSTAGE;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) piece(base, g);
+    for (int g = 0; g < 2 * NR; ++g) piece(base, g);
     advance();
   };
 
@@ -343,13 +354,13 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   for (int i = 0; i < 4; ++i) {
     const int ra = wm * 128 + i * 32 + fr;
     a_off[i] = ra * TROW;
-    a_sw[i] = (ra >> 2) & 3;
+    a_sw[i] = (ra >> SWSH) & (SLOTS - 1);
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rb = wn * 64 + i * 32 + fr;
     b_off[i] = TBM * TROW + rb * TROW;
-    b_sw[i] = (rb >> 2) & 3;
+    b_sw[i] = (rb >> SWSH) & (SLOTS - 1);
   }
 
 #ifdef SD_STAMP
@@ -361,42 +372,51 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #endif
   for (int s0 = 0; s0 < TNST - 1 && s0 < nk; ++s0) issue(s0);
   int st_rd = 0, st_wr = TNST - 1;
+  // SIMD partners (waves w and w + 4) are staggered: the first half issues its DMA pieces right after the
+  // barrier, the second half after its first 8 MFMAs, so one partner's DMA issue runs under the other's MFMAs.
+  // A piece costs its wave 85-90 cycles with four waves issuing together (in-kernel counters); the vector-memory
+  // path itself takes 13.5 cycles per piece at saturation (tools/micro/dma_rate.hip).  Finer schedules measured
+  // slower: four issue slots (after 0 / 4 / 8 / 12 MFMAs, two waves each) 973 vs 1040 TFLOP/s on 3072x3072,
+  // single pieces between the MFMA groups of one wave likewise.
   const bool early = __builtin_amdgcn_readfirstlane(wid) < 4;
   for (int kt = 0; kt < nk; ++kt) {
     SD_TSEG(3);
-    // 4 DMA pieces per thread per step; the two youngest steps may stay in flight
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // 2 NR DMA pieces per thread per step; the TNST - 2 youngest steps may stay in flight
+    if (TNST == 4) {
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     SD_TSEG(0);
     __builtin_amdgcn_s_barrier();
     SD_TSEG(1);
-    // SIMD partners (waves w and w+4) are staggered: the first half issues its DMA pieces right after
-    // the barrier, the second half after its first MFMA group, so one partner's DMA issue (~100 cycles
-    // per piece: the CU's vector-memory path, not the instruction count, paces it) runs under the
-    // other's MFMAs.  Spreading single pieces between MFMA groups of the SAME wave was slower.
     const bool more = kt + TNST - 1 < nk;
     if (more && early) issue(st_wr);
     SD_TSEG(2);
     const char* st = smem_raw + st_rd * TSTAGE;
-    h8 fa[2][4], fb[2][2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ls = 2 * kk + fh;
+    for (int pp = 0; pp < TBK / 32; ++pp) {          // pairs of 16-wide k slices
+      h8 fa[2][4], fb[2][2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[kk][i] = *reinterpret_cast<const h8*>(st + a_off[i] + ((ls ^ a_sw[i]) << 4));
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ls = 2 * (2 * pp + kk) + fh;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[kk][j] = *reinterpret_cast<const h8*>(st + b_off[j] + ((ls ^ b_sw[j]) << 4));
+        for (int i = 0; i < 4; ++i) fa[kk][i] = *reinterpret_cast<const h8*>(st + a_off[i] + ((ls ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[kk][j] = *reinterpret_cast<const h8*>(st + b_off[j] + ((ls ^ b_sw[j]) << 4));
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        }
+        if (pp == 0 && kk == 0 && more && !early) issue(st_wr);
+      }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
-    if (more && !early) issue(st_wr);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
     st_rd = st_rd == TNST - 1 ? 0 : st_rd + 1;
     st_wr = st_wr == TNST - 1 ? 0 : st_wr + 1;
   }
@@ -433,11 +453,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   }
 }
 
-template <typename TO>
+template <typename TO, int TBK>
 int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
   const long tiles_m = (a->M + TBM - 1) / TBM;
   const long tiles_n = (a->cout + TBN - 1) / TBN;
-  auto kern = conv_gemm_f16_t256_kernel<TO>;
+  auto kern = conv_gemm_f16_t256_kernel<TO, TBK>;
   static bool attr_set = false;
   if (!attr_set) {
     SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES));
@@ -529,7 +549,14 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   }();
   const bool wide = a->cout >= 1024;
   const int choice = forced >= 0 ? forced : (wide ? 2 : 0);
-  if (xa && choice == 2 && !(a->tee && a->tee_add)) return ya ? launch_t256<_Float16>(a, vec, stream) : launch_t256<float>(a, vec, stream);
+  static const int t256_k = [] {      // SD_T256_K=32|64: K step of the 256x256 kernel (diagnostic)
+    const char* e = getenv("SD_T256_K");
+    return e ? atoi(e) : SD_T256_K_DEFAULT;
+  }();
+  if (xa && choice == 2 && !(a->tee && a->tee_add)) {
+    if (t256_k == 64) return ya ? launch_t256<_Float16, 64>(a, vec, stream) : launch_t256<float, 64>(a, vec, stream);
+    return ya ? launch_t256<_Float16, 32>(a, vec, stream) : launch_t256<float, 32>(a, vec, stream);
+  }
   if (xa && ya) return launch<_Float16, _Float16>(a, vec, stream);
   if (xa && !ya) return launch<_Float16, float>(a, vec, stream);
   if (!xa && ya) return launch<float, _Float16>(a, vec, stream);

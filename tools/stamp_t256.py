@@ -17,9 +17,9 @@ lib.sd_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.sd_debug_read_stamps(buf, n) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.float64)[:, :4]
 nb = min(8192, ((M + 255) // 256) * ((cout + 255) // 256)); st = st[:nb]
-nk = cin // 32
+kb = int(os.environ.get("SD_T256_K", "32")); nk = cin // kb
 tot = st.sum(1)
-print(f"cin={cin} cout={cout} blocks={nb} ksteps={nk}: cycles per K step (wave 0, median over workgroups)")
+print(f"cin={cin} cout={cout} blocks={nb} ksteps={nk} (K step {kb}): cycles per K step (wave 0, median over workgroups)")
 for i, nm in enumerate(["DMA wait (vmcnt)", "barrier", "DMA issue", "LDS reads + MFMA"]):
     print(f"  {nm:20s} {np.median(st[:, i]) / nk:8.0f} cycles  ({np.median(st[:, i] / tot) * 100:5.1f} %)")
 print(f"  total                {np.median(tot) / nk:8.0f} cycles per K step (s_memtime ticks)")
