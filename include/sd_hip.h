@@ -135,12 +135,12 @@ typedef struct {
   const void* tee_add; int ld_ta; int ta_col0;
   int x_dtype; int y_dtype; /* SD_DT_*; 0 = f32 (the only choice for sd_conv1d_cl_f32) */
   /* Optional per-segment column statistics from the epilogue (the SE squeeze mean, the global mean / std
-   * of attentive pooling), so that y is not read back for them.  colstat: [ceil(M / 128)][4][cout] floats;
+   * of attentive pooling), so that y is not read back for them.  colstat: [ceil(M / 128)][6][cout] floats;
    * for every 128-row tile, sums over its (existing) rows of (y - shift) and (y - shift)^2, split at the
-   * segment boundary inside the tile: [sum first | sum second | sumsq first | sumsq second].
-   * sd_colstat_finish_dt turns them into [mean | std] per segment.
-   * Requirements (SD_ERR_UNSUPPORTED otherwise): T >= 128, cout a multiple of 256, relu / identity
-   * activation, per-channel bias, 16-byte aligned slices, no tee. */
+   * segment boundaries inside the tile (a tile spans up to three segments):
+   * [sum 1st | sum 2nd | sum 3rd | sumsq 1st | sumsq 2nd | sumsq 3rd].  sd_colstat_finish_dt turns them into
+   * [mean | std] per segment.  Requirements (SD_ERR_UNSUPPORTED otherwise): T >= 64, cout a multiple of 256,
+   * relu / identity activation, per-channel bias, 16-byte aligned slices, no tee. */
   float* colstat;
 } sd_conv_args;
 

@@ -454,8 +454,8 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
   }
   if (a->colstat) {
     const bool simple = (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg;
-    if (!(vec && simple && a->T >= 128 && a->cout % 256 == 0 && !a->tee))
-      return sd_set_error(SD_ERR_UNSUPPORTED, "sd_conv1d_cl_f32: colstat needs T >= 128, cout %% 256 == 0, relu/identity, per-channel bias, "
+    if (!(vec && simple && a->T >= 64 && a->cout % 256 == 0 && !a->tee))
+      return sd_set_error(SD_ERR_UNSUPPORTED, "sd_conv1d_cl_f32: colstat needs T >= 64, cout %% 256 == 0, relu/identity, per-channel bias, "
                           "aligned slices and no tee (T=%d cout=%d act=%d/%d)", a->T, a->cout, a->act, a->act2);
   }
   const long tiles_m = (a->M + BM - 1) / BM;

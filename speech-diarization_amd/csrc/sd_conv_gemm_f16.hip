@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
       }
     }
     __syncthreads();
-    sd_store_tile<TO, TBM / 2, TBN, 512, 1>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
+    sd_store_tile<TO, TBM / 2, TBN, 512, 1, 2>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
     __syncthreads();
   }
 }
@@ -532,8 +532,8 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   }
   if (a->colstat) {
     const bool simple = (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg;
-    if (!(vec && simple && a->T >= 128 && a->cout % 256 == 0 && !a->tee))
-      return sd_set_error(SD_ERR_UNSUPPORTED, "sd_conv1d_cl_f16: colstat needs T >= 128, cout %% 256 == 0, relu/identity, per-channel bias, "
+    if (!(vec && simple && a->T >= 64 && a->cout % 256 == 0 && !a->tee))
+      return sd_set_error(SD_ERR_UNSUPPORTED, "sd_conv1d_cl_f16: colstat needs T >= 64, cout %% 256 == 0, relu/identity, per-channel bias, "
                           "aligned slices and no tee (T=%d cout=%d act=%d/%d)", a->T, a->cout, a->act, a->act2);
   }
   const bool xa = a->x_dtype == SD_DT_F16, ya = a->y_dtype == SD_DT_F16;
@@ -553,7 +553,8 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
     const char* e = getenv("SD_T256_K");
     return e ? atoi(e) : SD_T256_K_DEFAULT;
   }();
-  if (xa && choice == 2 && !(a->tee && a->tee_add)) {
+  // (the 256x256 kernel: no tee_add epilogue, and column statistics only for tiles that span <= 2 segments)
+  if (xa && choice == 2 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128)) {
     if (t256_k == 64) return ya ? launch_t256<_Float16, 64>(a, vec, stream) : launch_t256<float, 64>(a, vec, stream);
     return ya ? launch_t256<_Float16, 32>(a, vec, stream) : launch_t256<float, 32>(a, vec, stream);
   }

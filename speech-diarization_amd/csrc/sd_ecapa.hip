@@ -178,7 +178,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // geometry allows (the Res2Net scratch s0 is dead and holds them), else from a pass over t2
     {
       sd_conv_args a = conv_of(blk.tdnn2, b.r, dt, C, 0, b.t2, dt, C, 0, M, T, SD_ACT_RELU);
-      const bool stat = colstat_ok && T >= 128 && C % 256 == 0 &&
+      const bool stat = colstat_ok && T >= 64 && C % 256 == 0 &&
                         sd_colstat_floats(M, C) * sizeof(float) <= (size_t)M * chunk * es;
       if (stat) a.colstat = static_cast<float*>(b.s0);
       SD_TRY(run_conv(a, stream));
@@ -200,7 +200,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   // epilogue (column sums in r, dead since the last block's tdnn2)
   {
     sd_conv_args a = conv_of(w->mfa, b.xcat, dt, Cm, 0, b.h, dt, Cm, 0, M, T, SD_ACT_RELU);
-    const bool stat = colstat_ok && T >= 128 && Cm % 256 == 0 &&
+    const bool stat = colstat_ok && T >= 64 && Cm % 256 == 0 &&
                       sd_colstat_floats(M, Cm) * sizeof(float) <= (size_t)M * C * es;
     if (stat) a.colstat = static_cast<float*>(b.r);
     SD_TRY(run_conv(a, stream));

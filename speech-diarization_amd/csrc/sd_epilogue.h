@@ -108,7 +108,7 @@ __device__ __forceinline__ void sd_store_tile_scalar(const sd_conv_args& p, cons
 // are all fetched before the first store (so the rows cannot go out in small chunks).
 // FULL: every row of the tile exists (straight-line code); otherwise the thread's first `np` passes
 // do (the tile hangs over row M) and the rest are predicated off.
-template <typename TO, int PASSES, int RPP, bool TEE, bool TADD, bool STAT, bool FULL>
+template <typename TO, int PASSES, int RPP, bool TEE, bool TADD, bool STAT, bool FULL, int PARTS = 3>
 __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float* c, int ldc, size_t row0, int n8,
                                               const float* b8, const float* s8, const float* h8, float lo,
                                               int rr0, int rb, float (*st)[8], int np) {
@@ -140,16 +140,18 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
       const bool live = FULL || c0 + i < np;
       if (live) SdOut<TO>::store8(y + (size_t)(c0 + i) * RPP * p.ldo, v[i]);
       if (STAT) {
-        // column statistics of this thread's rows, split at the segment boundary rb (tile-relative);
+        // column statistics of this thread's rows, split at the segment boundaries rb, rb + T (tile-relative);
         // taken about the pivot h8 (the BatchNorm shift) so that sum((x - pivot)^2) does not cancel
-        const bool second = rr0 + (c0 + i) * RPP >= rb;
+        const int row = rr0 + (c0 + i) * RPP;
+        const int part = (row >= rb ? 1 : 0) + (row >= rb + p.T ? 1 : 0);      // segment of the tile this row is in
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float x = live ? v[i][e] - h8[e] : 0.f;
-          st[0][e] += second ? 0.f : x;
-          st[1][e] += second ? x : 0.f;
-          st[2][e] += second ? 0.f : x * x;
-          st[3][e] += second ? x * x : 0.f;
+#pragma unroll
+          for (int q = 0; q < PARTS; ++q) {
+            st[q][e] += part == q ? x : 0.f;
+            st[PARTS + q][e] += part == q ? x * x : 0.f;
+          }
         }
       }
       if (TEE) {
@@ -168,13 +170,15 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
 // small launches: a 32-segment batch has 50.25 row tiles).
 // TEE_MODE: 2 = full (tee with or without tee_add), 1 = tee without tee_add only (the host never
 // selects such a kernel for a tee_add layer; saves the registers of the prefetched rows).
-template <typename TO, int ROWS, int COLS, int NT, int TEE_MODE = 2>
+// STAT_PARTS: segments a tile may span for the column statistics: 3 (T >= ROWS / 2) or 2 (T >= ROWS: the
+// 256x256 kernel, which has no registers for the third set of accumulators).
+template <typename TO, int ROWS, int COLS, int NT, int TEE_MODE = 2, int STAT_PARTS = 3>
 __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, int ldc, int m0, int n0, int tid, int vec) {
   constexpr int TPR = COLS / 8;     // threads per tile row
   constexpr int RPP = NT / TPR;     // rows per pass
   constexpr int PASSES = ROWS / RPP;
   static_assert(ROWS % RPP == 0, "tile rows must be a multiple of the rows covered per pass");
-  static_assert(4 * RPP * COLS <= ROWS * COLS, "column statistics are combined inside the C tile");
+  static_assert(2 * STAT_PARTS * RPP * COLS <= ROWS * COLS, "column statistics are combined inside the C tile");
   if (!vec) {
     sd_store_tile_scalar<TO, ROWS, COLS, NT>(p, Cs, ldc, m0, n0, tid);
     return;
@@ -234,16 +238,16 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
     else sd_store_rows<TO, PASSES, RPP, TEE_, TADD_, STAT_, false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, RB_, ST_, np);        \
   } while (0)
   if (p.colstat) {
-    // (host: only with relu / identity, a per-channel bias, cout % COLS == 0, no tee and T >= ROWS, so
-    // this branch is uniform over the workgroup, nobody returned above, and a tile spans <= 2 segments)
-    float st[4][8];
+    // (host: only with relu / identity, a per-channel bias, cout % COLS == 0, no tee and T >= ROWS / 2, so
+    // this branch is uniform over the workgroup, nobody returned above, and a tile spans <= 3 segments)
+    float st[2 * STAT_PARTS][8];          // [sum | sum of squares] x [first, second(, third) segment of the tile]
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 2 * STAT_PARTS; ++k)
 #pragma unroll
       for (int e = 0; e < 8; ++e) st[k][e] = 0.f;
     const int rb = p.T - m0 % p.T;          // first tile row of the next segment (>= ROWS: none)
     if (full) {
-      sd_store_rows<TO, PASSES, RPP, false, false, true, true>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, rb, st, PASSES);
+      sd_store_rows<TO, PASSES, RPP, false, false, true, true, STAT_PARTS>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, rb, st, PASSES);
     } else {
       // the one tile that hangs over row M: predicated stores, then a rolled pass over this thread's
       // existing rows for the statistics (keeps the unrolled variant's registers out of the common path)
@@ -252,30 +256,34 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
       for (int ps = 0; ps < np; ++ps) {
         float v[8];
         SdOut<float>::load8(c + ps * RPP * ldc, v);
-        const bool second = rr0 + ps * RPP >= rb;
+        const int row = rr0 + ps * RPP;
+        const int part = (row >= rb ? 1 : 0) + (row >= rb + p.T ? 1 : 0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float x = fmaxf(v[e] + b8[e], lo) * s8[e];     // = y - shift
-          st[0][e] += second ? 0.f : x;
-          st[1][e] += second ? x : 0.f;
-          st[2][e] += second ? 0.f : x * x;
-          st[3][e] += second ? x * x : 0.f;
+#pragma unroll
+          for (int q = 0; q < STAT_PARTS; ++q) {
+            st[q][e] += part == q ? x : 0.f;
+            st[STAT_PARTS + q][e] += part == q ? x * x : 0.f;
+          }
         }
       }
     }
     // combine the RPP row groups through LDS in a fixed order, then one writer per (quantity, column)
     __syncthreads();                        // every thread has consumed its part of the C tile
-    float* red = Cs;                        // [4][RPP][COLS]
+    float* red = Cs;                        // [2 * STAT_PARTS][RPP][COLS]
 #pragma unroll
-    for (int k = 0; k < 4; ++k) SdOut<float>::store8(red + ((size_t)k * RPP + rr0) * COLS + cq, st[k]);
+    for (int k = 0; k < 2 * STAT_PARTS; ++k) SdOut<float>::store8(red + ((size_t)k * RPP + rr0) * COLS + cq, st[k]);
     __syncthreads();
-    float* dst = p.colstat + (size_t)(m0 / ROWS) * 4 * p.cout + n0;
-    for (int idx = tid; idx < 4 * COLS; idx += NT) {
+    // colstat unit: [sum part 0..2 | sum of squares part 0..2][cout]; a 2-part kernel leaves slots 2 and 5 alone
+    float* dst = p.colstat + (size_t)(m0 / ROWS) * 6 * p.cout + n0;
+    for (int idx = tid; idx < 2 * STAT_PARTS * COLS; idx += NT) {
       const int k = idx / COLS, col = idx - k * COLS;
       float a = 0.f;
 #pragma unroll
       for (int g = 0; g < RPP; ++g) a += red[((size_t)k * RPP + g) * COLS + col];
-      dst[(size_t)k * p.cout + col] = a;
+      const int slot = k < STAT_PARTS ? k : 3 + (k - STAT_PARTS);
+      dst[(size_t)slot * p.cout + col] = a;
     }
     __syncthreads();                        // the caller may refill the tile
     return;

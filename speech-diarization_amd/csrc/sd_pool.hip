@@ -316,8 +316,8 @@ int check_cl_dt(const char* fn, const void* x, int dtype, int ld, int col0, int 
   return SD_OK;
 }
 // Column statistics left by the conv epilogue (sd_conv_args.colstat) -> per-segment mean (and std).
-// colstat [units][4][C]: sums of (y - pivot) and (y - pivot)^2 over each full 128-row tile, split at the
-// segment boundary inside the tile (a trailing partial tile counts its existing rows).  Thread =
+// colstat [units][6][C]: sums of (y - pivot) and (y - pivot)^2 over each 128-row tile, split at the
+// segment boundaries inside the tile (up to three segments: T >= 64) (a trailing partial tile counts its existing rows).  Thread =
 // (segment, channel); the tiles of a segment are added in ascending order.
 template <typename T>
 __global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __restrict__ cs, const float* __restrict__ pivot,
@@ -331,10 +331,10 @@ __global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __rest
   const float pv = pivot ? pivot[c] : 0.f;
   float s = 0.f, q = 0.f;
   for (int u = r0 / 128; u * 128 < r1; ++u) {
-    const int part = (u * 128) / Tn == b ? 0 : 1;   // this segment is the tile's first or second
-    const float* t = cs + (size_t)u * 4 * C + c;
+    const int part = b - (u * 128) / Tn;            // this segment is the tile's first, second or third (T >= 64)
+    const float* t = cs + (size_t)u * 6 * C + c;
     s += t[(size_t)part * C];
-    q += t[(size_t)(2 + part) * C];
+    q += t[(size_t)(3 + part) * C];
   }
   const float inv = 1.f / (float)Tn;
   const float m1 = s * inv;
@@ -427,14 +427,14 @@ int sd_split16_rows(const float* x, int ldx, int N, int D, int Dk, void* A, void
 
 extern "C" size_t sd_colstat_floats(int M, int cout) {
   if (M <= 0 || cout <= 0) return 0;
-  return (size_t)((M + 127) / 128) * 4 * (size_t)cout;
+  return (size_t)((M + 127) / 128) * 6 * (size_t)cout;
 }
 
 extern "C" int sd_colstat_finish_dt(const float* colstat, const float* pivot, const void* y, int y_dtype, int ldy, int y_col0,
                                     int B, int T, int C, int want_std, float eps, float* out, sd_stream_t stream) {
   SD_CHECK_ARG(colstat && y && out, "sd_colstat_finish_dt: null pointer");
   SD_CHECK_ARG(y_dtype == SD_DT_F32 || y_dtype == SD_DT_F16, "sd_colstat_finish_dt: y_dtype=%d", y_dtype);
-  SD_CHECK_ARG(B >= 0 && T >= 128 && C > 0, "sd_colstat_finish_dt: B=%d T=%d (>= 128) C=%d", B, T, C);
+  SD_CHECK_ARG(B >= 0 && T >= 64 && C > 0, "sd_colstat_finish_dt: B=%d T=%d (>= 64) C=%d", B, T, C);
   SD_CHECK_ARG((long)B * T < (1L << 31) && y_col0 >= 0 && y_col0 + C <= ldy, "sd_colstat_finish_dt: bad shape");
   if (B == 0) return SD_OK;
   SD_CHECK_ARG((long)B * ((C + 255) / 256) < (1L << 31), "sd_colstat_finish_dt: grid too large");

@@ -139,6 +139,10 @@ def test_fused_attention_pooling_refuses_what_it_does_not_cover(dev):
     (torch.float16, 3, 150, 64, 1024),     # 256x256 f16 kernel (two 128-row halves per tile)
     (torch.float16, 7, 301, 128, 1024),    # last 256-row tile: second half starts past the last row
     (torch.float16, 3, 201, 64, 1024),
+    (torch.float32, 9, 101, 64, 256),      # 1 s windows: a 128-row tile spans three segments
+    (torch.float32, 13, 64, 32, 256),      # shortest supported segments
+    (torch.float16, 9, 101, 64, 256),
+    (torch.float16, 11, 101, 64, 1024),    # wide output with T < 128: the 128x128 kernel takes it (three parts)
 ])
 def test_epilogue_column_statistics(dev, wdt, B, T, cin, cout):
     """SE squeeze mean / global mean+std straight from the conv epilogue == statistics of the stored output."""
@@ -156,7 +160,10 @@ def test_epilogue_column_statistics(dev, wdt, B, T, cin, cout):
                             shift=shift.to(dev))
     # the stored output does not change (to rounding: without colstat a launch this small takes the 32x32 split-K kernel)
     assert (y.float() - y_plain.float()).abs().max() <= 2e-3 * y_plain.float().abs().max() * (1.0 if wdt == torch.float16 else 1e-3)
-    assert bool(torch.isfinite(cs[:n_cs]).all()) and bool(torch.isnan(cs[n_cs:]).all())   # every tile wrote, nobody wrote past the end
+    units = cs[:n_cs].view(-1, 6, cout)           # [sum part 0..2 | sum of squares part 0..2]; part 2 only exists for T < 128
+    assert bool(torch.isfinite(units[:, [0, 1, 3, 4]]).all()) and bool(torch.isnan(cs[n_cs:]).all())   # every tile wrote, nobody wrote past the end
+    if T < 128:
+        assert bool(torch.isfinite(units).all())
     st = ops.colstat_finish(cs, y, B, T, pivot=shift.to(dev), want_std=True).cpu().double()
     mean_only = ops.colstat_finish(cs, y, B, T, pivot=shift.to(dev)).cpu().double()
     yr = y.cpu().double().view(B, T, cout)
@@ -168,10 +175,10 @@ def test_epilogue_column_statistics(dev, wdt, B, T, cin, cout):
 
 def test_epilogue_column_statistics_refuses_short_segments(dev):
     from speech_diarization_amd import ops
-    x = torch.zeros(3 * 64, 64, device=dev)
+    x = torch.zeros(5 * 50, 64, device=dev)
     w = ops.pack_weight(torch.zeros(256, 64, 1), dev)
     with pytest.raises(RuntimeError, match="colstat needs"):
-        ops.conv1d_cl(x, w, 64, cin=64, act="relu", colstat=torch.zeros(ops.colstat_floats(192, 256), device=dev))
+        ops.conv1d_cl(x, w, 50, cin=64, act="relu", colstat=torch.zeros(ops.colstat_floats(250, 256), device=dev))
 
 
 def test_pool_kernels_on_f16_activations(dev):
