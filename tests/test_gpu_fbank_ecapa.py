@@ -118,13 +118,17 @@ def test_ecapa_small_geometry_matches_oracle(dev, conv_kernel, width, B, n):
     assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max()
 
 
-def test_ecapa_full_geometry_matches_oracle(dev, conv_kernel):
-    """The spkrec-ecapa geometry (C=1024, 20.8 M parameters) on 2 s segments."""
+@pytest.mark.parametrize("B,n", [(4, 32000), (5, 16000), (2, 100000), (3, 9600)])
+def test_ecapa_full_geometry_matches_oracle(dev, conv_kernel, B, n):
+    """The spkrec-ecapa geometry (C=1024, 20.8 M parameters): the bench's 2 s segments, the reference's 1 s SCD /
+    reassignment windows (tiles spanning three segments), a long VAD segment as embed_segments pads them
+    (T = 626: attentive pooling falls back to conv + streaming pooling) and 0.6 s windows (T = 61: statistics from
+    the separate kernels)."""
     from oracle import pipeline_ref
     from speech_diarization_amd import synth
     from speech_diarization_amd.engine import EmbeddingEngine
     sd = synth.make_ecapa_state_dict(1234)
-    wav = synth.synthetic_segments(0, 4, 32000)
+    wav = synth.synthetic_segments(0, B, n)
     eng = EmbeddingEngine(sd, dev)
     got = eng.embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
     ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
