@@ -234,7 +234,9 @@ __device__ unsigned long long sd_stamp_buf[8192 * 8];
 // [512 rows] = 32 KB per stage, a 4-stage LDS-DMA ring (three K steps in flight), counted vmcnt
 // + raw barrier per step.  Swizzle for 64-byte rows: four rows share a 256-byte bank row, so
 // physical slot = logical slot ^ ((row >> 2) & 3) puts 16 consecutive rows on 16 distinct slots.
-// The 256x256 f32 C tile does not fit LDS: the epilogue runs once per 128-row half.
+// The 256x256 f32 C tile does not fit LDS: the epilogue runs once per 128-row half.  (A persistent walk over
+// the tiles, meant to let a tile's stores drain under the next K loop, measured no better: the loop state costs
+// 13-26 spilled registers in this 256-register kernel and the next tile's first vmcnt(0) waits for the stores anyway.)
 constexpr int TBM = 256;
 constexpr int TBN = 256;
 #ifndef SD_T256_K_DEFAULT
