@@ -3,7 +3,7 @@
 Function names, signatures and results follow the reference's `anti_stick_diarize.py`
 (`Segment`, `scd_split_segments` [REF :78-127], `embed_segments` [REF :130-172],
 `conservative_merge` [REF :273-330], `speaker_centroids` [REF :333-349],
-`_get_speech_windows` [REF :352-367], `frame_reassign` [REF :390-460], `merge_adjacent`
+`cluster_hdbscan` / `cluster_hdbscan_two_stage` [REF :175-270], `_get_speech_windows` [REF :352-367], `frame_reassign` [REF :390-460], `merge_adjacent`
 [REF :464-475], `diarize` [REF :493-560]).  What changes is where the work runs:
 
 * every function that embeds takes an optional `encode` callable (`wavs[B, n] -> [B, 192]`);
@@ -296,11 +296,15 @@ def diarize(wav: np.ndarray, sr: int = 16000, vad_on_thr: float = 0.6, vad_off_t
             scd_win_ms: float = 1000.0, scd_hop_ms: float = 200, scd_thr: float = 1.50, merge_max_gap_s: float = 0.5,
             merge_max_speech_s: float = 30.0, merge_mincos: float = 0.8, reseg: int = 1, cluster_cos: float = 0.70,
             encode: Encoder | None = None, vad_segments: Callable | None = None,
-            compat_reference_bugs: bool = False) -> list[Segment]:
+            compat_reference_bugs: bool = False, clusterer: str | Callable = "hdbscan_two_stage") -> list[Segment]:
     """VAD -> SCD split -> embed -> cluster -> conservative merge -> re-embed -> frame reassignment ->
     merge_adjacent, the stage order of [REF anti_stick_diarize.py:493-560] on an already loaded,
-    conditioned 16 kHz mono float32 signal.  Clustering is average-linkage AHC on the GPU cosine
-    affinity (the reference's HDBSCAN package is not installed here)."""
+    conditioned 16 kHz mono float32 signal.
+
+    `clusterer` selects what sits inside the reference's `cluster_hdbscan_two_stage(embs, min_cluster_size=2)`
+    [REF :536]: "hdbscan_two_stage" (default: the two-stage glue over `cluster.default_hdbscan_factory`),
+    "ahc" (the same glue with average-linkage AHC cut at `cluster_cos` injected as the clusterer), "ahc_affinity"
+    (single-stage AHC on the GPU cosine affinity), or a `clusterer_factory(**kwargs)` callable."""
     from . import cluster
     y = np.ascontiguousarray(wav, dtype=np.float32)
     vad_fn = vad_segments or silero_vad_segments
@@ -312,7 +316,15 @@ def diarize(wav: np.ndarray, sr: int = 16000, vad_on_thr: float = 0.6, vad_off_t
     speech = [Segment(s, e) for s, e in speech_t]
     speech2 = scd_split_segments(y, sr, speech, win_ms=scd_win_ms, hop_ms=scd_hop_ms, thr=scd_thr, encode=encode)
     embs = embed_segments(y, sr, speech2, encode=encode)
-    labels = cluster.relabel_by_first_appearance(cluster.ahc_cosine(cosine_affinity(embs, _on_gpu(encode)), cluster_cos))
+    if clusterer == "ahc_affinity":
+        raw = cluster.ahc_cosine(cosine_affinity(embs, _on_gpu(encode)), cluster_cos)
+    else:
+        factory = (None if clusterer == "hdbscan_two_stage" else
+                   cluster.AhcClusterer.factory(cluster_cos) if clusterer == "ahc" else clusterer)
+        if factory is not None and not callable(factory):
+            raise ValueError(f"clusterer must be 'hdbscan_two_stage', 'ahc', 'ahc_affinity' or a factory, got {clusterer!r}")
+        raw = cluster_hdbscan_two_stage(embs, min_cluster_size=2, clusterer_factory=factory)
+    labels = cluster.relabel_by_first_appearance(raw)
     for s, lab in zip(speech2, labels):
         s.spk = int(lab)
     merge_input = labels if compat_reference_bugs else embs
@@ -321,6 +333,19 @@ def diarize(wav: np.ndarray, sr: int = 16000, vad_on_thr: float = 0.6, vad_off_t
     embs3 = embed_segments(y, sr, speech3, encode=encode)
     speech4 = frame_reassign(y, sr, speech, speech3, embs3, smooth_step=0.10, win=1.0, encode=encode) if reseg else speech3
     return merge_adjacent(speech4, gap=merge_max_gap_s)
+
+
+def cluster_hdbscan(embs: np.ndarray, min_cluster_size: int = 2, clusterer_factory=None, use_gpu: bool = False) -> np.ndarray:
+    """[REF anti_stick_diarize.py:175-186]; the N x N cosine on the GPU when `use_gpu`."""
+    from . import cluster
+    aff = (lambda x: cosine_affinity(x, True)) if use_gpu else None
+    return cluster.cluster_hdbscan(embs, min_cluster_size, clusterer_factory, affinity=aff)
+
+
+def cluster_hdbscan_two_stage(embs: np.ndarray, min_cluster_size: int = 2, clusterer_factory=None) -> np.ndarray:
+    """[REF anti_stick_diarize.py:189-270] (restated in `cluster.cluster_hdbscan_two_stage`)."""
+    from . import cluster
+    return cluster.cluster_hdbscan_two_stage(embs, min_cluster_size, clusterer_factory)
 
 
 def cosine_affinity(embs: np.ndarray, use_gpu: bool) -> np.ndarray:

@@ -10,8 +10,11 @@ embedding work, and stays on the host with scikit-learn exactly as the reference
                    clustering threshold [REF diarization_baseline.py:37,248].
 * `spectral`     — SpectralClustering(affinity="precomputed") on max(K, 0)
                    (BASELINE.json configs[0] asks for spectral clustering).
-* `hdbscan_*`    — the reference's HDBSCAN variants [REF anti_stick_diarize.py:175-270]
-                   need the `hdbscan` package, which is not installed here: gated.
+* `cluster_hdbscan`, `cluster_hdbscan_two_stage` — the reference's own glue around a density
+                   clusterer [REF anti_stick_diarize.py:175-270], restated over an injectable
+                   `clusterer_factory`; the default is the `hdbscan` package when installed, else
+                   scikit-learn's HDBSCAN.  Golden-pinned against the reference function itself
+                   (tests/golden/cluster_two_stage.json).
 """
 from __future__ import annotations
 
@@ -104,17 +107,96 @@ def relabel_by_first_appearance(labels: np.ndarray) -> np.ndarray:
     return out
 
 
-def _hdbscan_cls():
+def default_hdbscan_factory(**kwargs):
+    """The density clusterer behind the reference's HDBSCAN call sites: the `hdbscan` package the
+    reference imports [REF anti_stick_diarize.py:14] when it is installed, else scikit-learn's
+    `sklearn.cluster.HDBSCAN` (the in-tree port of the same algorithm; same keyword names for the
+    four arguments the reference passes).  Returns an object with `fit_predict(X) -> labels`."""
     try:
         from hdbscan import HDBSCAN
-    except ImportError as e:  # pragma: no cover - depends on the environment
-        raise ImportError("the `hdbscan` package is not installed; use cluster.ahc_cosine / cluster.spectral") from e
-    return HDBSCAN
+    except ImportError:
+        from sklearn.cluster import HDBSCAN
+    return HDBSCAN(**kwargs)
 
 
-def hdbscan_precomputed(K, min_cluster_size: int = 2) -> np.ndarray:
-    """[REF anti_stick_diarize.py:175-186]: HDBSCAN(metric='precomputed') on 1 - K."""
-    HDBSCAN = _hdbscan_cls()
+class AhcClusterer:
+    """Average-linkage AHC as an injectable stand-in for an HDBSCAN object: `fit_predict` accepts what
+    the reference hands its clusterers, i.e. L2-normalised rows (metric "euclidean") or a precomputed
+    cosine-distance matrix (metric "precomputed"), and cuts at cosine `cos_thr`
+    [REF diar_diag.py:218-226].  Never selected implicitly: pass `clusterer_factory=AhcClusterer.factory(thr)`."""
+
+    def __init__(self, cos_thr: float = 0.70, metric: str = "euclidean", **_ignored):
+        self.cos_thr = float(cos_thr)
+        self.metric = metric
+
+    @classmethod
+    def factory(cls, cos_thr: float = 0.70):
+        return lambda **kw: cls(cos_thr, metric=kw.get("metric", "euclidean"))
+
+    def fit_predict(self, X) -> np.ndarray:
+        X = np.asarray(X, dtype=np.float64)
+        if self.metric == "precomputed":
+            return ahc_cosine(1.0 - X, self.cos_thr)
+        n = np.linalg.norm(X, axis=1, keepdims=True)
+        Xn = X / np.where(n > 0, n, 1.0)
+        return ahc_cosine(Xn @ Xn.T, self.cos_thr)
+
+
+def cluster_hdbscan(embs: np.ndarray, min_cluster_size: int = 2, clusterer_factory=None, affinity=None) -> np.ndarray:
+    """[REF anti_stick_diarize.py:175-186]: rows scaled by 1 / (norm + 1e-8), D = 1 - cosine_similarity,
+    HDBSCAN(min_cluster_size, min_samples=None, allow_single_cluster=True, metric="precomputed").fit_predict(D).
+    `affinity(X) -> K` lets the caller take the N x N product on the GPU (`ops.cosine_affinity`)."""
+    embs = np.asarray(embs)
+    embs_norm = embs / (np.linalg.norm(embs, axis=1, keepdims=True) + 1e-8)
+    if affinity is None:
+        from sklearn.metrics.pairwise import cosine_similarity as affinity
+    D = 1 - np.asarray(affinity(embs_norm))
+    factory = clusterer_factory or default_hdbscan_factory
+    clu = factory(min_cluster_size=min_cluster_size, min_samples=None, allow_single_cluster=True, metric="precomputed")
+    return np.asarray(clu.fit_predict(D))
+
+
+def hdbscan_precomputed(K, min_cluster_size: int = 2, clusterer_factory=None) -> np.ndarray:
+    """HDBSCAN(metric='precomputed') on 1 - K for an affinity that already exists [REF diar_diag.py:214-217]."""
     D = 1.0 - _as_f64_affinity(K)
-    return HDBSCAN(min_cluster_size=min_cluster_size, min_samples=None, allow_single_cluster=True,
-                   metric="precomputed").fit_predict(D)
+    factory = clusterer_factory or default_hdbscan_factory
+    return np.asarray(factory(min_cluster_size=min_cluster_size, min_samples=None, allow_single_cluster=True,
+                              metric="precomputed").fit_predict(D))
+
+
+def cluster_hdbscan_two_stage(embs: np.ndarray, min_cluster_size: int = 2, clusterer_factory=None) -> np.ndarray:
+    """The reference's two-stage clustering glue [REF anti_stick_diarize.py:189-270] over an injectable
+    clusterer (`clusterer_factory(**kwargs).fit_predict(X)`; default `default_hdbscan_factory`):
+
+    1. over-cluster the rows scaled by 1 / (norm + 1e-8) (euclidean) into micro-clusters [REF :199-214];
+       none found -> everything is speaker 0 [REF :216-218] (an empty float array for zero rows);
+    2. centroid = mean of the UN-normalised member rows of each micro-cluster, in label order [REF :220-236];
+    3. fewer centroids than `min_cluster_size` -> one speaker, else re-cluster the normalised centroids
+       with a second clusterer of the same settings [REF :240-255];
+    4. members inherit their centroid's label; members of a noise centroid and stage-1 noise stay -1
+       [REF :257-266].
+    """
+    embs = np.asarray(embs)
+    num_segments = embs.shape[0]
+    factory = clusterer_factory or default_hdbscan_factory
+    settings = dict(min_cluster_size=min_cluster_size, min_samples=None, metric="euclidean", allow_single_cluster=True)
+    embs_norm = embs / (np.linalg.norm(embs, axis=1, keepdims=True) + 1e-8)
+    stage1 = np.asarray(factory(**settings).fit_predict(embs_norm))
+    n_micro = int(np.max(stage1)) + 1
+    if n_micro < 1:
+        return np.zeros(num_segments, dtype=int) if num_segments > 0 else np.array([])
+    member_rows = [np.flatnonzero(stage1 == i) for i in range(n_micro)]
+    kept = [(i, rows) for i, rows in enumerate(member_rows) if rows.size]     # labels that actually occur
+    if not kept:
+        return np.zeros(num_segments, dtype=int)
+    centroids = np.array([np.mean(embs[rows], axis=0) for _, rows in kept])
+    if len(centroids) < min_cluster_size:
+        stage2 = np.zeros(len(centroids), dtype=int)
+    else:
+        cents_norm = centroids / (np.linalg.norm(centroids, axis=1, keepdims=True) + 1e-8)
+        stage2 = np.asarray(factory(**settings).fit_predict(cents_norm))
+    final = np.full(num_segments, -1, dtype=int)
+    for (_, rows), lab in zip(kept, stage2):
+        if lab != -1:
+            final[rows] = lab
+    return final

@@ -239,6 +239,9 @@ __device__ unsigned long long sd_stamp_buf[8192 * 8];
 // 13-26 spilled registers in this 256-register kernel and the next tile's first vmcnt(0) waits for the stores anyway.)
 constexpr int TBM = 256;
 constexpr int TBN = 256;
+#ifndef SD_T256_LATE
+#define SD_T256_LATE 1      // the second half of the waves issues its DMA pieces after this many groups of 8 MFMAs
+#endif
 #ifndef SD_T256_K_DEFAULT
 #define SD_T256_K_DEFAULT 64
 #endif
@@ -260,6 +263,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   constexpr int RSTEP = 512 / SLOTS;                 // rows covered by the 512 threads per piece: 128 or 64
   constexpr int NR = TBM / RSTEP;                    // pieces per operand per K step and thread: 2 or 4
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#ifdef SD_STAMP
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
@@ -367,6 +373,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 
 #ifdef SD_STAMP
   unsigned long long tacc[4] = {0, 0, 0, 0};   // wave 0's cycles in: DMA wait, barrier, DMA issue, LDS reads + MFMA
+  const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
 #define SD_TSEG(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; } while (0)
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #else
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
         }
-        if (pp == 0 && kk == 0 && more && !early) issue(st_wr);
+        if (2 * pp + kk == SD_T256_LATE - 1 && more && !early) issue(st_wr);
       }
     }
     st_rd = st_rd == TNST - 1 ? 0 : st_rd + 1;
@@ -424,8 +431,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   }
 #ifdef SD_STAMP
   SD_TSEG(3);
-  if (tid == 0 && blockIdx.x < 8192)
-    for (int i = 0; i < 4; ++i) sd_stamp_buf[blockIdx.x * 8 + i] = tacc[i];
+  const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
   __syncthreads();
 
@@ -453,6 +459,17 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
     sd_store_tile<TO, TBM / 2, TBN, 512, 1, 2>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
     __syncthreads();
   }
+#ifdef SD_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
+  if (tid == 0 && blockIdx.x < 8192) {
+    for (int i = 0; i < 4; ++i) sd_stamp_buf[blockIdx.x * 8 + i] = tacc[i];
+    sd_stamp_buf[blockIdx.x * 8 + 4] = t_loop0 - t_entry;    // prologue
+    sd_stamp_buf[blockIdx.x * 8 + 5] = t_exit - t_loop1;     // epilogue incl. store drain
+    sd_stamp_buf[blockIdx.x * 8 + 6] = t_exit - t_entry;
+    sd_stamp_buf[blockIdx.x * 8 + 7] = t_entry;
+  }
+#endif
 }
 
 template <typename TO, int TBK>

@@ -34,8 +34,9 @@ def asnorm_scores(query_embs: np.ndarray, ref_centers: np.ndarray, cohort_embs: 
 
 
 def cluster_embeddings(embs: np.ndarray, method: str = "hdbscan", cos_thr: float = 0.68) -> np.ndarray:
-    """"agglo": average-linkage AHC on 1 - cosine cut at 1 - cos_thr; "hdbscan" needs the hdbscan
-    package [REF diar_diag.py:213-229].  The N x N cosine runs on the GPU."""
+    """"agglo": average-linkage AHC on 1 - cosine cut at 1 - cos_thr; "hdbscan": HDBSCAN(min_cluster_size=6,
+    metric="precomputed") on 1 - cosine (`cluster.default_hdbscan_factory`) [REF diar_diag.py:213-229].
+    The N x N cosine runs on the GPU."""
     import torch
     from . import ops
     K = ops.cosine_affinity(torch.from_numpy(np.ascontiguousarray(embs, dtype=np.float32)).cuda()).cpu().numpy()

@@ -230,6 +230,63 @@ def main():
                        scores=scores, viterbi=rdd.viterbi_hmm(scores, alpha=0.9), viterbi_sticky=rdd.viterbi_hmm(scores), segments=segs, texts=texts))
     out["diar_diag"] = dd
 
+    # ---- cluster_hdbscan / cluster_hdbscan_two_stage: the reference's glue around a pluggable clusterer.
+    # `hdbscan` is absent, so the module-level HDBSCAN name is replaced by stand-ins: (a) a scripted class
+    # that returns prepared label vectors and records what it was constructed with and handed (this pins the
+    # normalisation, the centroid arithmetic, the degenerate returns and the map-back), (b) scikit-learn's
+    # HDBSCAN behind the same constructor (a real density clusterer through the whole function).
+    class Scripted:
+        script: list = []
+        log: list = []
+
+        def __init__(self, **kw):
+            self.kw = kw
+
+        def fit_predict(self, X):
+            X = np.asarray(X)
+            Scripted.log.append(dict(kwargs={k: (v if v is None or isinstance(v, (int, float, str, bool)) else str(v)) for k, v in self.kw.items()},
+                                     shape=list(X.shape), X=X.astype(np.float64)))
+            return np.asarray(Scripted.script.pop(0))
+
+    def embs_for(seed, sizes, dim=16, spread=0.15):
+        rows = []
+        for k, n in enumerate(sizes):
+            c = synth.normal(seed, f"golden.cl.c{k}", (1, dim)).astype(np.float64)
+            rows.append(3.0 * (1 + 0.3 * k) * c + spread * synth.normal(seed, f"golden.cl.n{k}", (n, dim)).astype(np.float64))
+        return np.concatenate(rows, axis=0)
+
+    cl = []
+    scripted_cases = [
+        # name, embs, min_cluster_size, scripted fit_predict outputs (stage 1[, stage 2])
+        ("no_micro_clusters", embs_for(31, [5]), 2, [[-1] * 5]),                                    # [REF :216-218]
+        ("one_centroid_lt_min_cluster_size", embs_for(32, [4, 3]), 2, [[0, 0, -1, 0, 0, -1, 0]]),   # [REF :243-245]
+        ("two_centroids_lt_mcs3", embs_for(33, [3, 3]), 3, [[0, 0, 0, 1, 1, -1]]),
+        ("stage2_noise_centroid", embs_for(34, [3, 3, 3]), 2, [[0, 0, 0, 1, 1, 1, 2, 2, -1], [0, -1, 0]]),   # [REF :261-266]
+        ("label_gap_and_merge", embs_for(35, [2, 2, 3, 2]), 2, [[0, 0, 3, 3, 1, -1, 1, 3, 3], [1, 1, 0]]),   # label 2 never occurs [REF :229]
+        ("all_merge_to_one", embs_for(36, [4, 4]), 2, [[0, 1, 0, 1, 2, 2, 3, 3], [0, 0, 0, 0]]),
+        ("zero_row_embedding", np.concatenate([embs_for(37, [3, 2]), np.zeros((1, 16))]), 2, [[0, 0, 0, 1, 1, 1], [0, 1]]),
+    ]
+    rasd.HDBSCAN = Scripted
+    for name, e, mcs, script in scripted_cases:
+        Scripted.script, Scripted.log = [list(v) for v in script], []
+        labels = rasd.cluster_hdbscan_two_stage(e, min_cluster_size=mcs)
+        cl.append(dict(name=name, kind="scripted", embs=e, min_cluster_size=mcs, script=script, calls=list(Scripted.log),
+                       labels=np.asarray(labels), labels_dtype=str(np.asarray(labels).dtype)))
+    # single-stage variant [REF :175-186]
+    e = embs_for(38, [4, 3])
+    Scripted.script, Scripted.log = [[0, 0, 0, 0, 1, 1, -1]], []
+    labels = rasd.cluster_hdbscan(e, min_cluster_size=2)
+    cl.append(dict(name="single_stage", kind="scripted_single", embs=e, min_cluster_size=2, script=[[0, 0, 0, 0, 1, 1, -1]],
+                   calls=list(Scripted.log), labels=np.asarray(labels), labels_dtype=str(np.asarray(labels).dtype)))
+    from sklearn.cluster import HDBSCAN as SkHDBSCAN
+    rasd.HDBSCAN = SkHDBSCAN
+    for seed, sizes, mcs in [(41, [12, 9, 7], 2), (42, [20, 15, 10, 5], 2), (43, [6, 6], 3), (44, [30], 2)]:
+        e = embs_for(seed, sizes, dim=24, spread=0.6)
+        labels = rasd.cluster_hdbscan_two_stage(e, min_cluster_size=mcs)
+        cl.append(dict(name=f"sklearn_hdbscan_{seed}", kind="sklearn", embs=e, min_cluster_size=mcs, labels=np.asarray(labels),
+                       labels_dtype=str(np.asarray(labels).dtype)))
+    out["cluster_two_stage"] = cl
+
     for name, payload in out.items():
         with open(os.path.join(HERE, f"{name}.json"), "w") as f:
             json.dump(jsonable(payload), f)

@@ -180,3 +180,58 @@ def test_diar_diag_score_helpers_match_reference(golden_dir, tmp_path):
         dd.save_json(tmp_path / "a.json", case["segments"], ["S0", "S1"])
         for k in ("srt", "csv", "json"):
             assert (tmp_path / f"a.{k}").read_text(encoding="utf-8") == case["texts"][k]
+
+
+# ---- cluster_hdbscan / cluster_hdbscan_two_stage [REF anti_stick_diarize.py:175-270]
+
+class _Scripted:
+    """Same stand-in the golden generator put in the reference's HDBSCAN slot: returns the prepared
+    label vectors and records constructor arguments and inputs."""
+
+    def __init__(self, script, log, **kw):
+        self.script, self.log, self.kw = script, log, kw
+
+    def fit_predict(self, X):
+        self.log.append(dict(kwargs=dict(self.kw), X=np.asarray(X, dtype=np.float64)))
+        return np.asarray(self.script.pop(0))
+
+
+def test_cluster_two_stage_matches_reference(golden_dir):
+    from speech_diarization_amd import cluster
+    cases = _load(golden_dir, "cluster_two_stage")
+    seen = set()
+    for c in cases:
+        embs = np.asarray(c["embs"], dtype=np.float64)
+        want = np.asarray(c["labels"], dtype=np.int64)
+        if c["kind"] == "sklearn":
+            # a real density clusterer through the whole function (scikit-learn's HDBSCAN on both sides)
+            from sklearn.cluster import HDBSCAN
+            got = asd.cluster_hdbscan_two_stage(embs, c["min_cluster_size"], clusterer_factory=lambda **kw: HDBSCAN(**kw))
+            assert np.array_equal(got, want), c["name"]
+            assert np.array_equal(asd.cluster_hdbscan_two_stage(embs, c["min_cluster_size"]), want)   # default factory
+            continue
+        script, log = [list(v) for v in c["script"]], []
+        factory = lambda **kw: _Scripted(script, log, **kw)   # noqa: E731
+        fn = cluster.cluster_hdbscan if c["kind"] == "scripted_single" else cluster.cluster_hdbscan_two_stage
+        got = fn(embs, c["min_cluster_size"], clusterer_factory=factory)
+        assert np.array_equal(got, want), c["name"]
+        assert str(np.asarray(got).dtype) == c["labels_dtype"]
+        assert not script, f"{c['name']}: the reference made {len(c['calls'])} clusterer calls"
+        assert len(log) == len(c["calls"])
+        for mine, ref in zip(log, c["calls"]):
+            assert mine["kwargs"] == ref["kwargs"]
+            np.testing.assert_allclose(mine["X"], np.asarray(ref["X"]), rtol=0, atol=1e-12)   # normalisation / centroids / 1 - cos
+        seen.add(c["name"])
+    # the degenerate branches the reference spells out
+    assert {"no_micro_clusters", "one_centroid_lt_min_cluster_size", "stage2_noise_centroid", "label_gap_and_merge"} <= seen
+
+
+def test_cluster_two_stage_with_injected_ahc_separates_speakers():
+    from speech_diarization_amd import cluster, synth
+    rows = []
+    for k in range(3):
+        c = synth.normal(7, f"ahc.c{k}", (1, 32)).astype(np.float64)
+        rows.append(4.0 * c + 0.2 * synth.normal(7, f"ahc.n{k}", (10, 32)))
+    embs = np.concatenate(rows)
+    labels = cluster.cluster_hdbscan_two_stage(embs, 2, clusterer_factory=cluster.AhcClusterer.factory(0.7))
+    assert len(set(labels.tolist())) == 3 and all(len(set(labels[10 * k: 10 * k + 10].tolist())) == 1 for k in range(3))

@@ -116,6 +116,7 @@ def test_config0_on_gpu_gives_the_cpu_rttm(small_encoder, tmp_path):
 def test_full_diarize_pipeline_runs_on_gpu(small_encoder):
     from speech_diarization_amd import anti_stick_diarize as asd, synth
     conv = synth.synthetic_conversation(30.0, 2, seed=5)
-    out = asd.diarize(conv.wav, 16000, scd_thr=3.0, cluster_cos=0.2)
-    assert out and all(isinstance(s, asd.Segment) and s.spk is not None and s.end > s.start for s in out)
+    for clusterer in ("hdbscan_two_stage", "ahc", "ahc_affinity"):      # the reference's glue over HDBSCAN / injected AHC; one-stage AHC
+        out = asd.diarize(conv.wav, 16000, scd_thr=3.0, cluster_cos=0.2, clusterer=clusterer)
+        assert out and all(isinstance(s, asd.Segment) and s.spk is not None and s.end > s.start for s in out), clusterer
     assert asd.diarize(np.zeros(32000, np.float32), 16000) == []                     # no speech -> []
