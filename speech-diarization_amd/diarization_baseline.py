@@ -151,8 +151,13 @@ def diarize_audio(audio_filepath: str | Path | dict, min_speech_duration_s: floa
                   min_speakers: int, max_speakers: int, rttm_filepath: str | Path | None = None, *,
                   encoder: Encoder | None = None, clustering: str = "spectral", clustering_threshold: float = 0.70,
                   window_s: float = 2.0, hop_s: float = 0.25, vad_scorer=None, center_embeddings: bool = True,
-                  return_details: bool = False) -> list[tuple[float, float, str | int]]:
-    """-> [(start_s, end_s, "SPEAKER_xx")], RTTM written to `rttm_filepath` when given."""
+                  return_details: bool = False, world: str | None = None) -> list[tuple[float, float, str | int]]:
+    """-> [(start_s, end_s, "SPEAKER_xx")], RTTM written to `rttm_filepath` when given.
+
+    `world="dist"` (under torchrun, after `dist.init_from_env()`): BASELINE.json configs[2].  Every rank runs the
+    host glue on the same audio, embeds only the windows `i mod W == rank` (`dist.shard_indices`), ONE
+    `all_gather_into_tensor` returns the full [N, 192] in window order to every rank, every rank clusters
+    (deterministic, N x 192 is tiny), rank 0 writes the RTTM.  The result is identical to `world=None`."""
     y, sr, uri = _load(audio_filepath)
     use_gpu = encoder is None
     if encoder is None:
@@ -169,7 +174,12 @@ def diarize_audio(audio_filepath: str | Path | dict, min_speech_duration_s: floa
     if speech:
         win = int(round(window_s * sr))
         starts, centres, regions = speech_windows(speech, len(y), sr, window_s, hop_s)
-        embs = encoder(gather_windows(y, starts, win))
+        if world is None:
+            embs = encoder(gather_windows(y, starts, win))
+        elif world == "dist":
+            embs = _embed_sharded(encoder, y, starts, win, use_gpu)
+        else:
+            raise ValueError(f"world must be None or 'dist', got {world!r}")
         # recording-level mean removal (first step of the reference's whiten_l2, [REF diar_diag.py:187-188]):
         # untrained / mismatched encoders put a large common component into every embedding
         K = cosine_affinity(cluster.center(embs) if center_embeddings else embs, use_gpu)
@@ -183,10 +193,30 @@ def diarize_audio(audio_filepath: str | Path | dict, min_speech_duration_s: floa
         labels = cluster.relabel_by_first_appearance(labels)
         segments = [(s, e, rttm.speaker_label(k)) for s, e, k in labels_to_turns(speech, centres, regions, labels)]
         details.update(labels=labels, embeddings=embs, affinity=K, window_starts=starts)
-    if rttm_filepath:
+    if rttm_filepath and (world is None or _rank() == 0):
         with open(rttm_filepath, "w") as f:
             rttm.write_rttm(segments, uri, f)
     return (segments, details) if return_details else segments
+
+
+def _rank() -> int:
+    from . import dist
+    return dist.world()[0]
+
+
+def _embed_sharded(encoder: Encoder, y: np.ndarray, starts: np.ndarray, win: int, use_gpu: bool) -> np.ndarray:
+    """Embed this rank's round-robin shard of the windows, all-gather the 192-d rows (RCCL when the process
+    group is "nccl": device tensors; gloo: host tensors), return all N rows in window order."""
+    import torch
+    from . import dist
+    rank, w = dist.world()
+    n = len(starts)
+    mine = dist.shard_indices(n, rank, w)
+    local = encoder(gather_windows(y, starts[mine], win)) if len(mine) else np.zeros((0, 192), np.float32)
+    t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
+    if use_gpu and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl":
+        t = t.cuda()
+    return dist.all_gather_embeddings(t, n).cpu().numpy()
 
 
 def expand_audios(root: Path):
