@@ -47,7 +47,7 @@ def parse():
                     help="f32: exact f32 MFMA (configs[1], the headline). f16: f16 operands / f32 accumulate (configs[4])")
     ap.add_argument("--no-f16-extra", action="store_true", help="skip the extra f16 measurement appended to the f32 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for each batch size of the CPU baseline sample")
     return ap.parse_args()
 
 
@@ -70,23 +70,34 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(state_dict, wav_dev, budget_s):
-    """The CPU oracle (torch f32: torch.stft fbank + F.conv1d ECAPA) on the host cores, batch 32
-    (the reference's embed_segments batch, [REF anti_stick_diarize.py:134])."""
+    """The CPU oracle (torch f32: torch.stft fbank + F.conv1d ECAPA) on the host cores, as SURVEY.md §8(d) /
+    BASELINE.md §3 prescribe: batches of 32 (the reference's embed_segments batch, [REF anti_stick_diarize.py:134])
+    and of 128 (its reassignment batch, [REF :398]), 20 warm-up segments, >= 200 timed segments per batch size
+    (bounded by `budget_s` seconds each).  `value` is the batch-32 rate."""
     from oracle.ecapa_ref import EcapaRef
     from oracle.pipeline_ref import encode_batch_ref
     cores = usable_cores()
     torch.set_num_threads(cores)
     net = EcapaRef(state_dict, torch.float32)
-    batch = 32
-    sample = wav_dev[: 16 * batch].cpu().numpy()
-    encode_batch_ref(state_dict, sample[:4], torch.float32, net)           # warm-up (allocator, oneDNN primitives)
-    done, t0 = 0, time.perf_counter()
-    while done < sample.shape[0] and (time.perf_counter() - t0) < budget_s:
-        encode_batch_ref(state_dict, sample[done:done + batch], torch.float32, net)
-        done += batch
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "segments/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} of the same synthetic 2 s segments, batch {batch}, torch-CPU f32 oracle, {dt:.1f} s"}
+    sample = wav_dev[:256].cpu().numpy()
+    encode_batch_ref(state_dict, sample[:20], torch.float32, net)           # 20 warm-up segments (allocator, oneDNN primitives)
+    rates = {}
+    for batch, n_seg in ((32, 224), (128, 256)):
+        done, t0 = 0, time.perf_counter()
+        while done < n_seg and (time.perf_counter() - t0) < budget_s:
+            encode_batch_ref(state_dict, sample[done % 256: done % 256 + batch], torch.float32, net)
+            done += batch
+        rates[batch] = (done, time.perf_counter() - t0)
+    d32, t32 = rates[32]
+    d128, t128 = rates[128]
+    try:
+        model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except (OSError, IndexError):
+        model = "unknown"
+    return {"value": d32 / t32, "unit": "segments/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{d32} of the same synthetic 2 s segments at batch 32 in {t32:.1f} s ({d32 / t32:.1f}/s) and {d128} at batch 128 in "
+                      f"{t128:.1f} s ({d128 / t128:.1f}/s), after 20 warm-up segments; torch-CPU f32 oracle on {model}",
+            "batch32": d32 / t32, "batch128": d128 / t128, "cpu_model": model}
 
 
 def load_profile_json(name):
@@ -126,8 +137,9 @@ def main():
     state_dict = synth.make_ecapa_state_dict(1234)
     engine = EmbeddingEngine(state_dict, dev, max_batch=args.micro_batch, precision=args.precision)
     S = args.segments
-    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
-    wav = (torch.randn((S, SAMPLES), generator=gen, device=dev, dtype=torch.float32) * 0.1).clamp_(-1.0, 1.0)
+    # generated on the device by the counter-based generator, seed 0, N(0, 0.1^2) clipped to
+    # [-1, 1]; rank r owns rows [r S, (r + 1) S) of the one stream
+    wav = synth.synthetic_segments_device(0, S, SAMPLES, dev, std=0.1, first_row=rank * S)
     n_total = S * world
     lo, hi = sdist.row_block(n_total, rank, world)
     aff = torch.empty((hi - lo, n_total), dtype=torch.float32, device=dev)
@@ -184,9 +196,9 @@ def main():
             "roofline": {"kernel": "conv_gemm_f16_kernel", "bound": "mfma", "achieved": c16_tf, "peak": F16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": c16_tf / F16_MFMA_PEAK_TFLOPS, "launches": c16_n,
                          "avg_launch_ms": c16_ms / max(c16_n, 1), "share_of_step_time": c16_ms * 1e-3 / dt16,
-                         # rocprofv3 --pmc pass of `bench.py --precision f16` (profiles/mfma_util_f16.json), not live
                          "mfma_util_pmc": {k: (v or {}).get("mfma_util") for k, v in load_profile_json("mfma_util_f16.json").items()
-                                           if k.startswith("conv_gemm_f16")}},
+                                           if k.startswith("conv_gemm_f16")},
+                         "mfma_util_pmc_source": "file profiles/mfma_util_f16.json (separate rocprofv3 --pmc pass of `bench.py --precision f16`); NOT measured in this run"},
         }
 
     if rank == 0:
@@ -201,7 +213,8 @@ def main():
             "metric": "segment-embeddings/sec (2 s @16 kHz)",
             "value": value,
             "unit": "segments/s",
-            "n_gpus": world,
+            "n_gpus": world if backend == "nccl" else min(world, n_dev),    # a gloo rehearsal may put several ranks on one card
+            "ranks": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -210,21 +223,24 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
+            "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none (single process)",
             "config": {
                 "workload": "configs[1]: 10k synthetic 2 s@16 kHz segments per GPU, HIP fbank + ECAPA-TDNN forward "
                             "(C=1024 spkrec-ecapa geometry, random-init seed 1234), all-gather of 192-d embeddings, "
                             "cosine affinity of the rank's row block on-device",
                 "segments_per_gpu": S, "samples_per_segment": SAMPLES, "micro_batch": args.micro_batch,
                 "affinity_rows_per_gpu": hi - lo, "affinity_cols": n_total,
-                "parallelism": f"segments sharded over {world} GPU(s), one all_gather_into_tensor per step",
+                "parallelism": f"segments sharded over {world} rank(s) on {min(world, n_dev)} GPU(s), one all_gather_into_tensor per step",
+                "gpus_visible": n_dev,
             },
             "roofline": {
                 "kernel": conv_kernel, "bound": "mfma",
                 "achieved": conv_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
                 "frac": conv_tflops / mfma_peak,
                 "traffic": traffic.get(conv_kernel),
-                # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass of this command (profiles/mfma_util.json), not live
+                "traffic_source": "file profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch); NOT measured in this run",
                 "mfma_util_pmc": (load_profile_json("mfma_util.json").get(conv_kernel) or {}).get("mfma_util"),
+                "mfma_util_pmc_source": "file profiles/mfma_util.json (separate rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass); NOT measured in this run",
                 "launches": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
                 "flops_per_launch": conv_flops / max(conv_n, 1),
                 "share_of_step_time": conv_ms * 1e-3 / dt,
@@ -233,6 +249,7 @@ def main():
                 "kernel": "fbank_logmel_kernel", "bound": "hbm",
                 "achieved": fb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb_gbs / HBM_PEAK_GBS,
                 "traffic": traffic.get("fbank_logmel_kernel"),
+                "traffic_source": "file profiles/traffic.json; NOT measured in this run",
                 "launches": fb_n, "avg_launch_ms": fb_ms / max(fb_n, 1),
                 "bytes_per_launch": fb_bytes / max(fb_n, 1),
                 "share_of_step_time": fb_ms * 1e-3 / dt,

@@ -142,16 +142,22 @@ def load() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
-        if not LIB_PATH.exists():
+        import os
+        lib_path = LIB_PATH
+        if os.environ.get("SD_HIP_LIB"):          # A/B experiment builds (build_native.py --variant); never set in product runs
+            lib_path = Path(os.environ["SD_HIP_LIB"])
+            if not lib_path.exists():
+                raise RuntimeError(f"SD_HIP_LIB={lib_path} does not exist")
+        if not lib_path.exists():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP hot path is not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
                 "There is deliberately no CPU fallback."
             )
-        lib = C.CDLL(str(LIB_PATH))
+        lib = C.CDLL(str(lib_path))
         missing = [name for name in PROTOTYPES if not hasattr(lib, name)]
         if missing:
-            raise RuntimeError(f"{LIB_PATH} lacks symbols declared in include/sd_hip.h: {missing}")
+            raise RuntimeError(f"{lib_path} lacks symbols declared in include/sd_hip.h: {missing}")
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.restype = res

@@ -46,8 +46,12 @@ def needs_build() -> bool:
     return STAMP.read_text().strip() != _fingerprint()
 
 
-def build(force: bool = False, verbose: bool = False, stamp: bool = False) -> Path:
-    """stamp=True: diagnostic build with in-kernel timeline stamps (-DSD_STAMP); never ship or time it."""
+def build(force: bool = False, verbose: bool = False, stamp: bool = False, variant: str | None = None, cflags: str = "") -> Path:
+    """stamp=True: diagnostic build with in-kernel timeline stamps (-DSD_STAMP); never ship or time it.
+    variant="name": an A/B build with extra `cflags` into variants/libsd_hip_<name>.so (selected at run time with
+    SD_HIP_LIB=<path>; experiments only: the product library is always libsd_hip.so)."""
+    if variant:
+        return _build_variant(variant, cflags, verbose)
     if not force and not stamp and not needs_build():
         return LIB_PATH
     obj_dir = CSRC / "obj"
@@ -86,6 +90,40 @@ def build(force: bool = False, verbose: bool = False, stamp: bool = False) -> Pa
     return LIB_PATH
 
 
+def _build_variant(name: str, cflags: str, verbose: bool) -> Path:
+    out_dir = PKG_DIR / "variants"
+    obj_dir = CSRC / "obj" / f"v_{name}"
+    out_dir.mkdir(exist_ok=True)
+    obj_dir.mkdir(parents=True, exist_ok=True)
+    common = [_hipcc(), f"--offload-arch={OFFLOAD_ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}",
+              "-Wall", "-Wno-unused-function"] + cflags.split()
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = obj_dir / (Path(src).stem + ".o")
+        objs.append(str(obj))
+        cmd = common + ["-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0 or verbose:
+            sys.stderr.write(f"--- {src}\n{out}\n")
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed; see output above")
+    lib = out_dir / f"libsd_hip_{name}.so"
+    res = subprocess.run([_hipcc(), f"--offload-arch={OFFLOAD_ARCH}", "-shared", "-fPIC", "-o", str(lib)] + objs,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout)
+        raise RuntimeError("link failed")
+    return lib
+
+
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, stamp="--stamp" in sys.argv)
+    variant, cflags = None, ""
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        variant, cflags = sys.argv[i + 1], (sys.argv[i + 2] if len(sys.argv) > i + 2 else "")
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, stamp="--stamp" in sys.argv, variant=variant, cflags=cflags)
     print(path)

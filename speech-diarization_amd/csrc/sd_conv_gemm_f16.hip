@@ -223,48 +223,50 @@ __device__ unsigned long long sd_stamp_buf[8192 * 8];
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),  \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-// ------------------------------------------------------------------------------------------
-// 256x256 tile for the large square convs, fed by LDS-DMA (global_load_lds_dwordx4 writes the operand
-// tiles straight into an LDS ring, no VGPR staging).  What paces every f16 variant is the CU's
-// vector-memory path: a 1 KB DMA piece takes ~57 cycles of it, i.e. ~18 B/clk per CU of operand ingest
-// (in-kernel cycle counters, tools/stamp_t256.py: a K step is 1789 cycles for 32 KB and 1024 cycles of
-// MFMA), so the lever is bytes per flop, and this tile has half those of the 128x128 kernel above.  (A 256x128 LDS-DMA variant and a ninth "L2 prefetch" wave were tried and
-// dropped: 800 vs 864 TFLOP/s on 3072x3072, and slower, respectively.)  8 waves as 2 (M) x 4 (N), each
-// 128x64 = 4x2 MFMA tiles (128 accumulator registers); K step 32 halfs, i.e. 64-byte LDS rows,
-// [512 rows] = 32 KB per stage, a 4-stage LDS-DMA ring (three K steps in flight), counted vmcnt
-// + raw barrier per step.  Swizzle for 64-byte rows: four rows share a 256-byte bank row, so
-// physical slot = logical slot ^ ((row >> 2) & 3) puts 16 consecutive rows on 16 distinct slots.
-// The 256x256 f32 C tile does not fit LDS: the epilogue runs once per 128-row half.  (A persistent walk over
-// the tiles, meant to let a tile's stores drain under the next K loop, measured no better: the loop state costs
-// 13-26 spilled registers in this 256-register kernel and the next tile's first vmcnt(0) waits for the stores anyway.)
 constexpr int TBM = 256;
 constexpr int TBN = 256;
-#ifndef SD_T256_LATE
-#define SD_T256_LATE 1      // the second half of the waves issues its DMA pieces after this many groups of 8 MFMAs
-#endif
-#ifndef SD_T256_K_DEFAULT
-#define SD_T256_K_DEFAULT 64
-#endif
-constexpr int TLDS_BYTES = 131072;                 // the operand ring: 4 stages of K = 32 or 2 stages of K = 64
-static_assert((TBM / 2) * TBN * 4 <= TLDS_BYTES, "half C tile must fit in the ring");
-// TBK = 64 (128-byte rows): a DMA piece lands 8 rows and reads 8 FULL 128-byte cache lines.  With TBK = 32 a
-// piece reads half of 16 lines, and the other halves are fetched again one K step later: the L1 / vector-memory
-// path then moves twice the lines per useful byte (tools/micro/dma_rate.hip: whole lines stream at 76 B/clk/CU
-// from L2; the TBK = 32 loop was held at 18 B/clk).
+constexpr int R3_A_STAGE = TBM * 128;                 // [256 rows][64 halfs]
+constexpr int R3_B_STAGE = TBN * 128;
+constexpr int R3_B_BASE = 3 * R3_A_STAGE;
+constexpr int R3_LDS_BYTES = R3_B_BASE + 2 * R3_B_STAGE;   // 163 840 = all of the CU's LDS
+static_assert(R3_LDS_BYTES == 160 * 1024, "ring fills the LDS exactly");
+static_assert((TBM / 2) * TBN * 4 <= R3_LDS_BYTES, "half C tile must fit in the ring");
 
-template <typename TO, int TBK>
+// ------------------------------------------------------------------------------------------
+// 256x256 tile for the wide outputs (cout >= 1024: C -> C, 3C -> 3C), fed by LDS-DMA (global_load_lds_dwordx4 writes the
+// operand tiles straight into an LDS ring, no VGPR staging).  8 waves as 2 (M) x 4 (N), each 128 x 64 = 8 x 4 tiles of
+// v_mfma_f32_16x16x32_f16 (128 accumulator registers); K step 64 halfs = 128-byte rows, so a DMA piece (one wave
+// instruction, 1 KB) lands 8 whole rows and reads 8 FULL cache lines.  Swizzle: two rows share a 256-byte bank row;
+// physical 16-byte slot = logical slot ^ ((row >> 1) & 7) makes the ds_read_b128 fragment reads conflict-free
+// (applied on the DMA's per-lane SOURCE address, the LDS side of a DMA is lane-linear).
+//
+// What round 2 measured on this kernel and what the structure answers (tools/sweep_f16.py, tools/stamp_t256.py;
+// 1 005 000 rows; 3072 x 3072 / 1024 x 1024, TFLOP/s on random data):
+// * The chip is power-limited here: the same binary on zero-filled operands runs 1490 instead of 1140 (the in-kernel
+//   clock, s_memtime / s_memrealtime, reads 1.75-1.9 GHz on random data).  Cycles saved return about 2/3 as time, energy
+//   saved returns in full.  v_mfma_f32_16x16x32_f16 instead of 32x32x16: same flops per cycle, +6 % (1071 -> 1140): the
+//   chip holds a higher clock on it (1.87 vs 1.75 GHz).
+// * The DMA costs 28 % (1486 with the K loop's DMA removed vs 1073), and it is the CU-side issue / LDS-write path, not
+//   memory: with every tile reading the same 256 rows of both operands (all L2 hits) the rate is unchanged (1082).
+//   A wave issues no MFMA while it issues its 8 pieces (550-850 cycles with four waves issuing together).
+// * Ring depth by operand: the 160 KB of LDS hold THREE stages of A (activations: streamed from HBM) and TWO of B
+//   (weights: L2 / Infinity-Cache resident).  Waves 0-3 fetch the weights of step k + 1, waves 4-7 (their SIMD
+//   partners) the activations of step k + 2 (vmcnt(8): one step stays in flight across the barrier), each at a point
+//   of the step where the partner has MFMAs to issue.  (Two 64 KB stages, both operands by all waves: 1053 / 924.)
+// * LDS fragment reads are software-pipelined under the MFMAs: a K step is four half-slices (k slice of 32 x upper /
+//   lower 64 rows of the wave's 128): 4 A + 4 B fragments -> 16 MFMAs; two register sets per operand; the reads of
+//   half-slice h + 1 are issued in front of the MFMAs of h, and the barrier that opens step k + 1 sits in front of
+//   the LAST half-slice's MFMAs of step k, so the first reads of the next step are covered too: 1140 -> 1227 / 1027.
+// * Measured and not kept: s_setprio around the MFMA groups (-2 %), static priority for waves 4-7 (-3 %), the roles
+//   swapped between the wave halves (-3 %), issuing the activation pieces later in the step (each later slot -2..-4 %).
+// The 256x256 f32 C tile does not fit LDS: the epilogue runs once per 128-row half.
+template <typename TO>
 __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec) {
-  constexpr int TROW = TBK * 2;                      // bytes per staged row: 64 or 128
-  constexpr int SLOTS = TROW / 16;                   // 16-byte slots per row: 4 or 8
-  constexpr int SWSH = TROW == 64 ? 2 : 1;           // rows per 256-byte bank row = 1 << SWSH
-  constexpr int TSTAGE = (TBM + TBN) * TROW;         // 32 KB or 64 KB
-  constexpr int TNST = TLDS_BYTES / TSTAGE;          // 4 or 2
-  constexpr int RPI = 1024 / TROW;                   // rows one wave instruction lands: 16 or 8
-  constexpr int RSTEP = 512 / SLOTS;                 // rows covered by the 512 threads per piece: 128 or 64
-  constexpr int NR = TBM / RSTEP;                    // pieces per operand per K step and thread: 2 or 4
+  constexpr int TBK = 64;
+  constexpr int TROW = 128;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 #ifdef SD_STAMP
-  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), r_entry = __builtin_amdgcn_s_memrealtime();
 #endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -282,58 +284,58 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   const int tile_m = wg / n_tiles;
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
-  // staging role: thread (r0 = tid / SLOTS, ps = tid % SLOTS) fills physical slot ps of A rows r0 + RSTEP i and
-  // of the same B rows; one wave-instruction writes RPI whole rows (1 KB) of LDS
-  const int r0 = tid / SLOTS;
-  const int ps = tid % SLOTS;
-  int a_seg[NR], a_t[NR], a_ls[NR];
-  const _Float16* aptr[NR];
-  const _Float16* wptr[NR];
+  // staging role: within its group of 256 threads, thread (r0 = lt / 8, ps = lt % 8) fills physical 16-byte slot ps of rows
+  // r0 + 32 i (i < 8) of ITS operand: waves 0-3 the weights, waves 4-7 the activations.  The slot holds logical k chunk
+  // ps ^ ((row >> 1) & 7), and (row >> 1) & 7 does not depend on i.
+  const bool bload = __builtin_amdgcn_readfirstlane(wid) < 4;
+  const int lt = tid & 255;
+  const int r0 = lt >> 3;
+  const int ls8 = ((lt & 7) ^ ((r0 >> 1) & 7)) * 8;
   const int ktot = p.taps * p.cin_pad;
-  const _Float16* W = static_cast<const _Float16*>(p.w);
-#pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const int row = r0 + RSTEP * i;
-    const int ls = (ps ^ ((row >> SWSH) & (SLOTS - 1))) * 8;    // logical k offset (halfs) that belongs in this lane's slot
-    int m = m0 + row;
-    m = m < p.M ? m : p.M - 1;
-    const int seg = (m / p.T) * p.T;
-    a_seg[i] = seg;
-    a_t[i] = m - seg;
-    a_ls[i] = ls;
-    int n = n0 + row;
-    n = n < p.cout ? n : p.cout - 1;
-    wptr[i] = W + (size_t)n * ktot + ls;
-  }
   const int nk = p.taps * (p.cin_pad / TBK);
   const int half = p.taps / 2;
+  const _Float16* ptr[8];
   const _Float16* X = static_cast<const _Float16*>(p.x) + p.a_col0;
   auto set_tap = [&](int tap) {
     const int delta = (tap - half) * p.dil;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      int tt = a_t[i] + delta;
+    for (int i = 0; i < 8; ++i) {
+      int m = m0 + r0 + 32 * i;
+      m = m < p.M ? m : p.M - 1;
+      const int seg = (m / p.T) * p.T;
+      int tt = m - seg + delta;
       tt = tt < 0 ? -tt : tt;
       tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
-      aptr[i] = X + (size_t)(a_seg[i] + tt) * p.lda;
+      ptr[i] = X + (size_t)(seg + tt) * p.lda;
     }
   };
-  int ld_tap = 0, ld_c0 = 0;
-  set_tap(0);
-  const int dst_a = (wid * RPI) * TROW;                 // + RSTEP * i rows
-  const int dst_b = TBM * TROW + (wid * RPI) * TROW;
-  // DMA piece g of a K step: g < NR -> A rows r0 + RSTEP g; else B rows r0 + RSTEP (g - NR)
-  auto piece = [&](char* base, int g) {
-    if (g < NR) {
-      const int col = ld_c0 + a_ls[g];
-      SD_GLDS16(aptr[g] + (col < p.cin ? col : 0), base + dst_a + g * RSTEP * TROW);
-    } else {
-      SD_GLDS16(wptr[g - NR], base + dst_b + (g - NR) * RSTEP * TROW);
-    }
-  };
-  auto advance = [&]() {
+  if (bload) {
+    const _Float16* W = static_cast<const _Float16*>(p.w);
 #pragma unroll
-    for (int i = 0; i < NR; ++i) wptr[i] += TBK;
+    for (int i = 0; i < 8; ++i) {
+      int n = n0 + r0 + 32 * i;
+      n = n < p.cout ? n : p.cout - 1;
+      ptr[i] = W + (size_t)n * ktot + ls8;
+    }
+  } else {
+    set_tap(0);
+  }
+  int ld_tap = 0, ld_c0 = 0;
+  char* const dst = smem_raw + ((wid & 3) * 8) * TROW;
+  auto issue_b = [&](int st) {
+    char* base = dst + R3_B_BASE + st * R3_B_STAGE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      SD_GLDS16(ptr[i], base + i * 32 * TROW);
+      ptr[i] += TBK;
+    }
+  };
+  auto issue_a = [&](int st) {
+    char* base = dst + st * R3_A_STAGE;
+    const int col = ld_c0 + ls8;
+    const int acol = col < p.cin ? col : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) SD_GLDS16(ptr[i] + acol, base + i * 32 * TROW);
     ld_c0 += TBK;
     if (ld_c0 >= p.cin_pad) {
       ld_c0 = 0;
@@ -341,117 +343,88 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
       if (ld_tap < p.taps) set_tap(ld_tap);
     }
   };
-  auto issue = [&](int stage) {
-    char* base = smem_raw + stage * TSTAGE;
-#pragma unroll
-    for (int g = 0; g < 2 * NR; ++g) piece(base, g);
-    advance();
-  };
 
-  f32x16 acc[4][2];
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v acc[8][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ab_sw = (fr >> 1) & 7;
+  const char* const a_base = smem_raw + (wm * 128 + fr) * TROW;
+  const char* const b_base = smem_raw + R3_B_BASE + (wn * 64 + fr) * TROW;
+  // byte offset of this lane's 16 bytes inside a row, for k slice 0 / 1
+  const int so0 = (fq ^ ab_sw) << 4, so1 = ((4 + fq) ^ ab_sw) << 4;
 
-  const int fr = lane & 31, fh = lane >> 5;
-  int a_off[4], a_sw[4], b_off[2], b_sw[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = wm * 128 + i * 32 + fr;
-    a_off[i] = ra * TROW;
-    a_sw[i] = (ra >> SWSH) & (SLOTS - 1);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rb = wn * 64 + i * 32 + fr;
-    b_off[i] = TBM * TROW + rb * TROW;
-    b_sw[i] = (rb >> SWSH) & (SLOTS - 1);
-  }
+  h8 fa0[4], fa1[4], fb0[4], fb1[4];
+#define P3_READ_A(dst_, stage_, so_, g_)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+      dst_[i] = *reinterpret_cast<const h8*>(a_base + (stage_) * R3_A_STAGE + (4 * (g_) + i) * 16 * TROW + (so_))
+#define P3_READ_B(dst_, stage_, so_)                                                                            \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+      dst_[j] = *reinterpret_cast<const h8*>(b_base + (stage_) * R3_B_STAGE + j * 16 * TROW + (so_))
+#define P3_MMA(g_, a_, b_)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
+        acc[4 * (g_) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_[i], b_[j], acc[4 * (g_) + i][j], 0, 0, 0)
 
 #ifdef SD_STAMP
-  unsigned long long tacc[4] = {0, 0, 0, 0};   // wave 0's cycles in: DMA wait, barrier, DMA issue, LDS reads + MFMA
   const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
-#define SD_TSEG(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; } while (0)
-  unsigned long long tprev = __builtin_amdgcn_s_memtime();
-#else
-#define SD_TSEG(i) do { } while (0)
 #endif
-  for (int s0 = 0; s0 < TNST - 1 && s0 < nk; ++s0) issue(s0);
-  int st_rd = 0, st_wr = TNST - 1;
-  // SIMD partners (waves w and w + 4) are staggered: the first half issues its DMA pieces right after the
-  // barrier, the second half after its first 8 MFMAs, so one partner's DMA issue runs under the other's MFMAs.
-  // A piece costs its wave 85-90 cycles with four waves issuing together (in-kernel counters); the vector-memory
-  // path itself takes 13.5 cycles per piece at saturation (tools/micro/dma_rate.hip).  Finer schedules measured
-  // slower: four issue slots (after 0 / 4 / 8 / 12 MFMAs, two waves each) 973 vs 1040 TFLOP/s on 3072x3072,
-  // single pieces between the MFMA groups of one wave likewise.
-  const bool early = __builtin_amdgcn_readfirstlane(wid) < 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    SD_TSEG(3);
-    // 2 NR DMA pieces per thread per step; the TNST - 2 youngest steps may stay in flight
-    if (TNST == 4) {
-      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    SD_TSEG(0);
-    __builtin_amdgcn_s_barrier();
-    SD_TSEG(1);
-    const bool more = kt + TNST - 1 < nk;
-    if (more && early) issue(st_wr);
-    SD_TSEG(2);
-    const char* st = smem_raw + st_rd * TSTAGE;
-#pragma unroll
-    for (int pp = 0; pp < TBK / 32; ++pp) {          // pairs of 16-wide k slices
-      h8 fa[2][4], fb[2][2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ls = 2 * (2 * pp + kk) + fh;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[kk][i] = *reinterpret_cast<const h8*>(st + a_off[i] + ((ls ^ a_sw[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[kk][j] = *reinterpret_cast<const h8*>(st + b_off[j] + ((ls ^ b_sw[j]) << 4));
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-        }
-        if (2 * pp + kk == SD_T256_LATE - 1 && more && !early) issue(st_wr);
-      }
-    }
-    st_rd = st_rd == TNST - 1 ? 0 : st_rd + 1;
-    st_wr = st_wr == TNST - 1 ? 0 : st_wr + 1;
+  if (bload) {
+    issue_b(0);
+  } else {
+    issue_a(0);
+    if (nk > 1) issue_a(1);
   }
+  int sa = 0, sb = 0;                      // stages of step kt
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- barrier(kt): this step's stages have landed, every wave has finished reading the previous step's
+    if (bload || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");      // the activations of step kt + 1 stay in flight
+    __builtin_amdgcn_s_barrier();
+    const int sa2 = sa == 0 ? 2 : sa - 1;                                  // (sa + 2) % 3 = the A stage of step kt - 1
+    P3_READ_A(fa0, sa, so0, 0);
+    P3_READ_B(fb0, sb, so0);
+    if (kt > 0) { P3_MMA(1, fa1, fb1); }                                   // deferred half-slice 3 of step kt - 1
+    if (bload && kt + 1 < nk) issue_b(sb ^ 1);
+    // ---- half-slice 0
+    P3_READ_A(fa1, sa, so0, 1);
+    P3_MMA(0, fa0, fb0);
+    if (!bload && kt + 2 < nk) issue_a(sa2);
+    // ---- half-slice 1
+    P3_READ_A(fa0, sa, so1, 0);
+    P3_READ_B(fb1, sb, so1);
+    P3_MMA(1, fa1, fb0);
+    // ---- half-slice 2 (half-slice 3 runs behind the next barrier)
+    P3_READ_A(fa1, sa, so1, 1);
+    P3_MMA(0, fa0, fb1);
+    sa = sa == 2 ? 0 : sa + 1;
+    sb ^= 1;
+  }
+  P3_MMA(1, fa1, fb1);
+#undef P3_READ_A
+#undef P3_READ_B
+#undef P3_MMA
 #ifdef SD_STAMP
-  SD_TSEG(3);
   const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
   __syncthreads();
 
-  // ---- epilogue, one 128-row half at a time: the owning waves stage raw accumulators as a
-  // [128][256] f32 tile in the ring, then all 512 threads run sd_store_tile on it
   float* Cs = reinterpret_cast<float*>(smem_raw);
-  const int hrow = (lane >> 5) * 4;
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm) {
     if (wm == hm) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int cl = wn * 64 + ni * 32 + (lane & 31);
+      for (int ni = 0; ni < 4; ++ni) {
+        const int cl = wn * 64 + ni * 16 + fr;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = mi * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-            Cs[rl * TBN + cl] = acc[mi][ni][r];
-          }
+          for (int r = 0; r < 4; ++r) Cs[(mi * 16 + fq * 4 + r) * TBN + cl] = acc[mi][ni][r];
         }
       }
     }
@@ -462,29 +435,29 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #ifdef SD_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
-  if (tid == 0 && blockIdx.x < 8192) {
-    for (int i = 0; i < 4; ++i) sd_stamp_buf[blockIdx.x * 8 + i] = tacc[i];
-    sd_stamp_buf[blockIdx.x * 8 + 4] = t_loop0 - t_entry;    // prologue
-    sd_stamp_buf[blockIdx.x * 8 + 5] = t_exit - t_loop1;     // epilogue incl. store drain
-    sd_stamp_buf[blockIdx.x * 8 + 6] = t_exit - t_entry;
-    sd_stamp_buf[blockIdx.x * 8 + 7] = t_entry;
+  if (tid == 0 && blockIdx.x < 8192) {     // [prologue, K loop, epilogue incl. store drain, total] cycles, total in 100 MHz ticks
+    sd_stamp_buf[blockIdx.x * 8 + 0] = t_loop0 - t_entry;
+    sd_stamp_buf[blockIdx.x * 8 + 1] = t_loop1 - t_loop0;
+    sd_stamp_buf[blockIdx.x * 8 + 2] = t_exit - t_loop1;
+    sd_stamp_buf[blockIdx.x * 8 + 3] = t_exit - t_entry;
+    sd_stamp_buf[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime() - r_entry;
   }
 #endif
 }
 
-template <typename TO, int TBK>
+template <typename TO>
 int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
   const long tiles_m = (a->M + TBM - 1) / TBM;
   const long tiles_n = (a->cout + TBN - 1) / TBN;
-  auto kern = conv_gemm_f16_t256_kernel<TO, TBK>;
+  auto kern = conv_gemm_f16_t256_kernel<TO>;
   static bool attr_set = false;
   if (!attr_set) {
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES));
+    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS_BYTES));
     attr_set = true;
   }
   {
     SdProfScope prof(SD_PROF_CONV_GEMM, stream, 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), TLDS_BYTES, stream, *a, vec);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), R3_LDS_BYTES, stream, *a, vec);
   }
   SD_CHECK_LAUNCH("conv_gemm_f16_t256_kernel");
   return SD_OK;
@@ -568,15 +541,9 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   }();
   const bool wide = a->cout >= 1024;
   const int choice = forced >= 0 ? forced : (wide ? 2 : 0);
-  static const int t256_k = [] {      // SD_T256_K=32|64: K step of the 256x256 kernel (diagnostic)
-    const char* e = getenv("SD_T256_K");
-    return e ? atoi(e) : SD_T256_K_DEFAULT;
-  }();
   // (the 256x256 kernel: no tee_add epilogue, and column statistics only for tiles that span <= 2 segments)
-  if (xa && choice == 2 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128)) {
-    if (t256_k == 64) return ya ? launch_t256<_Float16, 64>(a, vec, stream) : launch_t256<float, 64>(a, vec, stream);
-    return ya ? launch_t256<_Float16, 32>(a, vec, stream) : launch_t256<float, 32>(a, vec, stream);
-  }
+  if (xa && choice == 2 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128))
+    return ya ? launch_t256<_Float16>(a, vec, stream) : launch_t256<float>(a, vec, stream);
   if (xa && ya) return launch<_Float16, _Float16>(a, vec, stream);
   if (xa && !ya) return launch<_Float16, float>(a, vec, stream);
   if (!xa && ya) return launch<float, _Float16>(a, vec, stream);

@@ -152,6 +152,40 @@ def synthetic_segments(seed: int, batch: int, n_samples: int, std: float = 0.1) 
     return np.clip(x, -1.0, 1.0)
 
 
+def synthetic_segments_device(seed: int, batch: int, n_samples: int, device, std: float = 0.1, first_row: int = 0, chunk_rows: int = 500):
+    """`synthetic_segments` generated ON the device (counter-based generator, seed 0,
+    N(0, std^2) clipped to [-1, 1]): the same splitmix64 counter stream in int64 torch arithmetic, Box-Muller in
+    float64.  Rows [first_row, first_row + batch) of the stream, so ranks can own disjoint rows of one data set.
+    Equal to the numpy generator up to the device's float64 log / cos rounding (<= 1 f32 ulp)."""
+    import torch
+    key = ((seed & 0xFFFFFFFF) << 32) ^ (zlib.crc32(f"seg.{n_samples}".encode()) & 0xFFFFFFFF)
+
+    def i64(v: int) -> int:                      # two's-complement view of a 64-bit constant
+        v &= 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(x, k: int):                          # logical shift right on int64
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def mix(x):
+        x = x + i64(0x9E3779B97F4A7C15)
+        z = (x ^ lsr(x, 30)) * i64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * i64(0x94D049BB133111EB)
+        return z ^ lsr(z, 31)
+
+    def unit(ctr):
+        bits = mix(mix(ctr ^ i64(key)) + i64(key))
+        return (lsr(bits, 11).to(torch.float64) + 0.5) * (1.0 / (1 << 53))
+
+    out = torch.empty((batch, n_samples), dtype=torch.float32, device=device)
+    for lo in range(0, batch, chunk_rows):
+        hi = min(batch, lo + chunk_rows)
+        idx = torch.arange((first_row + lo) * n_samples, (first_row + hi) * n_samples, dtype=torch.int64, device=device)
+        z = torch.sqrt(-2.0 * torch.log(unit(idx * 2))) * torch.cos(2.0 * math.pi * unit(idx * 2 + 1))
+        out[lo:hi] = (std * z).to(torch.float32).clamp_(-1.0, 1.0).view(hi - lo, n_samples)
+    return out
+
+
 # ---------------------------------------------------------------- synthetic conversations
 
 @dataclass

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--T", type=int, default=201)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--colstat", action="store_true")
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS check: same cycles, less switching energy)")
     ap.add_argument("shapes", nargs="+")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -25,8 +26,8 @@ def main():
         K, N = f[0], f[1]
         taps = f[2] if len(f) > 2 else 1
         dil = f[3] if len(f) > 3 else 1
-        x = (torch.randn(M, K, device=dev) * 0.5).half()
-        w = torch.randn(N, K, taps) / (K * taps) ** 0.5
+        x = torch.zeros(M, K, device=dev, dtype=torch.float16) if a.zeros else (torch.randn(M, K, device=dev) * 0.5).half()
+        w = torch.zeros(N, K, taps) if a.zeros else torch.randn(N, K, taps) / (K * taps) ** 0.5
         wp = ops.pack_weight(w, dev, torch.float16)
         bias = torch.randn(N, device=dev); scale = torch.rand(N, device=dev) + 0.5; shift = torch.randn(N, device=dev)
         out = torch.empty(M, N, device=dev, dtype=torch.float16)
