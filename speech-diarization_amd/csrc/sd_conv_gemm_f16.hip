@@ -232,6 +232,115 @@ constexpr int R3_LDS_BYTES = R3_B_BASE + 2 * R3_B_STAGE;   // 163 840 = all of t
 static_assert(R3_LDS_BYTES == 160 * 1024, "ring fills the LDS exactly");
 static_assert((TBM / 2) * TBN * 4 <= R3_LDS_BYTES, "half C tile must fit in the ring");
 
+// ---- register epilogue of the 256x256 kernel (DIRECT): see the kernel's comment
+__device__ __forceinline__ unsigned sd_pack_h2(float a, float b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 v;
+  v[0] = (_Float16)a;
+  v[1] = (_Float16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4); every lane gets the total
+__device__ __forceinline__ float sd_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+// acc[mi][nj][r] = y[row0 + 16 mi + fr][col0 + 16 nj + 4 fq + r] before bias; the wave owns rows [row0, row0 + 128) (one
+// column-statistics unit) and channels [col0, col0 + 64)
+template <typename TO, typename ACC>
+__device__ __forceinline__ void sd_direct_epilogue(const sd_conv_args& p, ACC (&acc)[8][4], int row0, int col0, int fr, int fq) {
+  const float lo = p.act == SD_ACT_RELU ? 0.f : -INFINITY;
+  TO* const Y = static_cast<TO*>(p.y) + p.o_col0;
+  const int rb = p.T - row0 % p.T;                 // first unit-relative row of the next segment (>= 128: none)
+  float* const cs = p.colstat ? p.colstat + (size_t)(row0 / 128) * 6 * p.cout : nullptr;
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {                 // pairs of 16-channel tiles
+    float b[2][4], s[2][4], h[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int c = col0 + 16 * (2 * jp + t) + 4 * fq;
+      const int cl = c < p.cout ? c : 0;           // channels past cout (cout % 8 == 0): loads clamped, nothing stored
+      const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 sv = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cl) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 hv = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { b[t][r] = bv[r]; s[t][r] = sv[r]; h[t][r] = hv[r]; }
+    }
+    float st[2][2][2][4];                          // [tile of the pair][sum | sum of squares][segment part][channel]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[t][k][q][r] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int m = row0 + 16 * mi + fr;
+      const bool live = m < p.M;
+      float v[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[t][r] = fmaxf(acc[mi][2 * jp + t][r] + b[t][r], lo) * s[t][r] + h[t][r];
+      if (cs) {
+        const int part = 16 * mi + fr >= rb ? 1 : 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = live ? v[t][r] - h[t][r] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              st[t][0][q][r] += part == q ? x : 0.f;
+              st[t][1][q][r] += part == q ? x * x : 0.f;
+            }
+          }
+      }
+      if constexpr (sizeof(TO) == 2) {
+        // lane row q = fq holds channels 4 q .. 4 q + 3 of both tiles; after the swaps it holds 8 consecutive channels
+        // of ONE tile: rows 0 / 2 of the even tile (channels 0-7 / 8-15), rows 1 / 3 of the odd tile
+        const auto w0 = __builtin_amdgcn_permlane16_swap(sd_pack_h2(v[0][0], v[0][1]), sd_pack_h2(v[1][0], v[1][1]), false, false);
+        const auto w1 = __builtin_amdgcn_permlane16_swap(sd_pack_h2(v[0][2], v[0][3]), sd_pack_h2(v[1][2], v[1][3]), false, false);
+        const int c8 = col0 + 16 * (2 * jp + (fq & 1)) + 8 * (fq >> 1);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifdef SD_DIAG_NO_STORE      // timing-only diagnostic build: the stores predicated off by a value the compiler cannot see through
+        if (live && c8 < p.cout && p.dil == 12345) *reinterpret_cast<u32x4*>(Y + (size_t)m * p.ldo + c8) = u32x4{w0[0], w1[0], w0[1], w1[1]};
+#else
+        if (live && c8 < p.cout) *reinterpret_cast<u32x4*>(Y + (size_t)m * p.ldo + c8) = u32x4{w0[0], w1[0], w0[1], w1[1]};
+#endif
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int c = col0 + 16 * (2 * jp + t) + 4 * fq;
+          if (live && c < p.cout) *reinterpret_cast<f32x4*>(Y + (size_t)m * p.ldo + c) = f32x4{v[t][0], v[t][1], v[t][2], v[t][3]};
+        }
+      }
+    }
+    if (cs) {
+      // colstat unit: [sum part 0..2 | sum of squares part 0..2][cout]; this kernel's tiles span <= 2 segments
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float tot[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tot[r] = sd_row16_sum(st[t][k][q][r]);
+            if (fr == 0)
+              *reinterpret_cast<f32x4*>(cs + (size_t)(3 * k + q) * p.cout + col0 + 16 * (2 * jp + t) + 4 * fq) = f32x4{tot[0], tot[1], tot[2], tot[3]};
+          }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // 256x256 tile for the wide outputs (cout >= 1024: C -> C, 3C -> 3C), fed by LDS-DMA (global_load_lds_dwordx4 writes the
 // operand tiles straight into an LDS ring, no VGPR staging).  8 waves as 2 (M) x 4 (N), each 128 x 64 = 8 x 4 tiles of
@@ -260,7 +369,13 @@ static_assert((TBM / 2) * TBN * 4 <= R3_LDS_BYTES, "half C tile must fit in the 
 // * Measured and not kept: s_setprio around the MFMA groups (-2 %), static priority for waves 4-7 (-3 %), the roles
 //   swapped between the wave halves (-3 %), issuing the activation pieces later in the step (each later slot -2..-4 %).
 // The 256x256 f32 C tile does not fit LDS: the epilogue runs once per 128-row half.
-template <typename TO>
+// DIRECT: the MFMA operands are swapped (D = W . X^T: accumulator ROWS are output channels, its columns time rows),
+// so a lane holds 4 CONSECUTIVE channels of one output row per 16x16 tile and the epilogue runs from registers:
+// bias -> ReLU -> BatchNorm affine in f32, f16 pairs, one v_permlane16_swap per dword joins the two 8-byte halves a
+// lane pair holds into 16 bytes, 16-byte row-contiguous stores (a wave writes whole 128-byte lines), and the column
+// statistics are per-lane sums over the wave's 8 row tiles reduced across 16 lanes with DPP: no LDS round trip, no
+// workgroup barrier.  For the plain epilogue only (ReLU / identity, per-channel bias, no tee): the host selects it.
+template <typename TO, bool DIRECT>
 __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec) {
   constexpr int TBK = 64;
   constexpr int TROW = 128;
@@ -369,7 +484,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #define P3_MMA(g_, a_, b_)                                                                                      \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-        acc[4 * (g_) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_[i], b_[j], acc[4 * (g_) + i][j], 0, 0, 0)
+        acc[4 * (g_) + i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(b_[j], a_[i], acc[4 * (g_) + i][j], 0, 0, 0)   \
+                                      : __builtin_amdgcn_mfma_f32_16x16x32_f16(a_[i], b_[j], acc[4 * (g_) + i][j], 0, 0, 0)
 
 #ifdef SD_STAMP
   const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
@@ -412,26 +528,30 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #ifdef SD_STAMP
   const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (DIRECT) {
+    sd_direct_epilogue<TO>(p, acc, m0 + wm * 128, n0 + wn * 64, fr, fq);
+  } else {
   __syncthreads();
-
-  float* Cs = reinterpret_cast<float*>(smem_raw);
-#pragma unroll
-  for (int hm = 0; hm < 2; ++hm) {
-    if (wm == hm) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int cl = wn * 64 + ni * 16 + fr;
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(mi * 16 + fq * 4 + r) * TBN + cl] = acc[mi][ni][r];
+  
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+  #pragma unroll
+    for (int hm = 0; hm < 2; ++hm) {
+      if (wm == hm) {
+  #pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int cl = wn * 64 + ni * 16 + fr;
+  #pragma unroll
+          for (int mi = 0; mi < 8; ++mi) {
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(mi * 16 + fq * 4 + r) * TBN + cl] = acc[mi][ni][r];
+          }
         }
       }
+      __syncthreads();
+      sd_store_tile<TO, TBM / 2, TBN, 512, 1, 2>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
+      __syncthreads();
     }
-    __syncthreads();
-    sd_store_tile<TO, TBM / 2, TBN, 512, 1, 2>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
-    __syncthreads();
-  }
+}
 #ifdef SD_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
@@ -445,11 +565,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #endif
 }
 
-template <typename TO>
+template <typename TO, bool DIRECT>
 int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
   const long tiles_m = (a->M + TBM - 1) / TBM;
   const long tiles_n = (a->cout + TBN - 1) / TBN;
-  auto kern = conv_gemm_f16_t256_kernel<TO>;
+  auto kern = conv_gemm_f16_t256_kernel<TO, DIRECT>;
   static bool attr_set = false;
   if (!attr_set) {
     SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS_BYTES));
@@ -542,8 +662,15 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   const bool wide = a->cout >= 1024;
   const int choice = forced >= 0 ? forced : (wide ? 2 : 0);
   // (the 256x256 kernel: no tee_add epilogue, and column statistics only for tiles that span <= 2 segments)
-  if (xa && choice == 2 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128))
-    return ya ? launch_t256<_Float16>(a, vec, stream) : launch_t256<float>(a, vec, stream);
+  if (xa && choice == 2 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128)) {
+    static const bool direct_ok = [] {     // SD_T256_DIRECT=0: the LDS-staged epilogue for every layer (A/B runs)
+      const char* e = getenv("SD_T256_DIRECT");
+      return !(e && e[0] == '0');
+    }();
+    const bool plain = vec && (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg && !a->tee;
+    if (plain && direct_ok) return ya ? launch_t256<_Float16, true>(a, vec, stream) : launch_t256<float, true>(a, vec, stream);
+    return ya ? launch_t256<_Float16, false>(a, vec, stream) : launch_t256<float, false>(a, vec, stream);
+  }
   if (xa && ya) return launch<_Float16, _Float16>(a, vec, stream);
   if (xa && !ya) return launch<_Float16, float>(a, vec, stream);
   if (!xa && ya) return launch<float, _Float16>(a, vec, stream);
