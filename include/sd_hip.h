@@ -14,7 +14,7 @@
  *   sd_ecapa_*            replaces  speechbrain ECAPA_TDNN forward inside
  *                                   EncoderClassifier.encode_batch
  *                                   [REF speech_encode.py:73-78] [REF ecapa_annote.py:22]
- *   sd_conv1d_cl_f32 / _f16, sd_seg_mean_std_*, sd_se_scale_residual_*, sd_asp_pool_*,
+ *   sd_conv1d_cl_f32 / _f16, sd_res2net_chain_f16, sd_seg_mean_std_*, sd_se_scale_residual_*, sd_asp_pool_*,
  *   sd_asp_attend_pool_dt, sd_colstat_finish_dt
  *                         the layer operators sd_ecapa_forward is built from: speechbrain's Conv1d /
  *                         TDNNBlock / SEBlock / AttentiveStatisticsPooling as reached from the same
@@ -48,7 +48,7 @@ typedef void* sd_stream_t; /* hipStream_t */
 #define SD_ERR_WORKSPACE (-3)
 #define SD_ERR_HIP (-4)
 
-#define SD_ABI_VERSION 3
+#define SD_ABI_VERSION 4
 
 int sd_abi_version(void);
 const char* sd_last_error(void);
@@ -233,6 +233,16 @@ typedef struct {
   sd_layer asp_conv;   /* att -> mfa */
   sd_layer fc;         /* 2*mfa -> emb, asp_bn folded in */
 } sd_ecapa_weights;
+
+/* The Res2Net chain of one SE-Res2Net block as one kernel, in place on the tdnn1 output r [B*T][ld] (f16):
+ *   y_1 = TDNN_1(c_1), y_j = TDNN_j(c_j + y_{j-1}) (j = 2..n), c_j = columns [128 j, 128 j + 128) of r, y_j written
+ * over c_j; TDNN = BatchNorm(ReLU(conv_{k=3, dilation}(.) + bias)), "same" reflect padding inside each T-row segment.
+ * layers: host array of n sd_layer (f16 packed weights, 128 -> 128, k = 3, one dilation).  Replaces, for speechbrain's
+ * Res2NetBlock inside encode_batch [REF speech_encode.py:77], n launches of sd_conv1d_cl_f16 with the tee epilogue.
+ * sd_res2net_chain_supported: chunk == 128, taps == 3, 1 <= n <= 7, dilation < T <= 212 (three [T][128] f16 buffers
+ * in the 160 KB LDS); the entry returns SD_ERR_UNSUPPORTED (nothing launched) otherwise. */
+int sd_res2net_chain_supported(int T, int chunk, int n, int taps, int dil);
+int sd_res2net_chain_f16(void* r, int ld, int B, int T, const sd_layer* layers, int n, sd_stream_t stream);
 
 size_t sd_ecapa_workspace_bytes(const sd_ecapa_weights* w, int B, int T);
 

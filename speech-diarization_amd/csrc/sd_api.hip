@@ -1,6 +1,9 @@
 // Error reporting, library identity and the N x N cosine-affinity entry point.
 #include "sd_common.h"
+#include <atomic>
 #include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -25,10 +28,24 @@ extern "C" int sd_device_count(void) {
   return n;
 }
 
+hipError_t sd_func_max_lds(const void* func, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  const auto key = std::make_pair(dev, func);
+  if (done.count(key)) return hipSuccess;
+  e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.insert(key);
+  return e;
+}
+
 // ---------------------------------------------------------------- event profiling
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; double work; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 std::vector<ProfRec> g_prof;       // records in use
 std::vector<hipEvent_t> g_pool;    // recycled events
 std::mutex g_prof_mu;

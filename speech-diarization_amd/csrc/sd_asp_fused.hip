@@ -187,11 +187,7 @@ int launch_f16(const void* a1, const void* wc, const void* h, int ldh, int B, in
   auto kern = asp_attend_pool_f16_kernel<TPW>;
   const size_t lds = (size_t)(CPB / 2) * WLD * sizeof(_Float16);
   static_assert((size_t)(CPB / 2) * WLD * sizeof(_Float16) >= (size_t)4 * CPB * 4 * sizeof(float), "statistics must fit in the weight tile");
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * (C / CPB))), dim3(256), lds, s, static_cast<const _Float16*>(a1),
                      static_cast<const _Float16*>(wc), static_cast<const _Float16*>(h), ldh, T, C, eps, out);
   SD_CHECK_LAUNCH("asp_attend_pool_f16_kernel");
@@ -326,11 +322,7 @@ int launch_f32(const void* a1, const void* wc, const void* h, int ldh, int B, in
   auto kern = asp_attend_pool_f32_kernel<NT>;
   const size_t lds = (size_t)NT * 16 * FLD * sizeof(float);
   const int cpb = C % 512 == 0 ? 512 : 256;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * (C / cpb))), dim3(512), lds, s, static_cast<const float*>(a1),
                      static_cast<const float*>(wc), static_cast<const float*>(h), ldh, T, C, cpb, eps, out);
   SD_CHECK_LAUNCH("asp_attend_pool_f32_kernel");

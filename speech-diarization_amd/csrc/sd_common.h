@@ -40,6 +40,11 @@ struct SdProfScope {
   hipStream_t stream;
 };
 
+// hipFuncSetAttribute(func, MaxDynamicSharedMemorySize, bytes) once per (device, kernel): thread-safe, keyed by the
+// calling thread's current device, so a second GPU in the same process or two threads racing the first call
+// (the reference's web UI calls the pipeline from a worker thread) both get the attribute set before the launch.
+hipError_t sd_func_max_lds(const void* func, int bytes);
+
 static inline bool sd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float sd_wave_max(float v) {

@@ -476,14 +476,8 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
     return e ? atoi(e) : SD_F32_DMA_DEFAULT;
   }();
   const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);   // the C tile of the epilogue needs BM * LDC <= this
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_kernel<false>), (int)lds));
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_kernel<true>), (int)lds));
   static const int order = [] {
     const char* e = getenv("SD_TILE_ORDER");
     return e ? atoi(e) : 1;

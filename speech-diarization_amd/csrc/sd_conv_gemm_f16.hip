@@ -570,11 +570,7 @@ int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
   const long tiles_m = (a->M + TBM - 1) / TBM;
   const long tiles_n = (a->cout + TBN - 1) / TBN;
   auto kern = conv_gemm_f16_t256_kernel<TO, DIRECT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS_BYTES));
-    attr_set = true;
-  }
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), R3_LDS_BYTES));
   {
     SdProfScope prof(SD_PROF_CONV_GEMM, stream, 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), R3_LDS_BYTES, stream, *a, vec);
@@ -588,11 +584,7 @@ int launch(const sd_conv_args* a, int vec, hipStream_t stream) {
   const long tiles_m = (a->M + BM - 1) / BM;
   const long tiles_n = (a->cout + BN - 1) / BN;
   auto kern = conv_gemm_f16_kernel<TA, TO>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_BYTES));
-    attr_set = true;
-  }
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), STAGE_BYTES));
   {
     SdProfScope prof(SD_PROF_CONV_GEMM, stream, 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), STAGE_BYTES, stream, *a, vec);

@@ -157,22 +157,34 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   const void* xin = b.x0; int ldin = C, colin = 0;
   for (int i = 0; i < w->n_blocks; ++i) {
     const sd_se_res2_block& blk = w->blocks[i];
-    // tdnn1 -> r; chunk 1 is also teed to s0 as the first Res2Net input
+    // Res2Net chain: y_j = TDNN_j(c_j + y_{j-1}), written over chunk j of r.  f16: one kernel per block keeps the
+    // segment's chain state in LDS (sd_res2net_f16.hip); otherwise (f32, or a segment too long for LDS) one conv per
+    // step, chunk 1 teed to s0 by tdnn1 and the adds c_{j+1} + y_j produced by each conv's epilogue.
+    static const bool chain_ok = [] {     // SD_RES2_FUSED=0: A/B switch for measurements
+      const char* e = getenv("SD_RES2_FUSED");
+      return !(e && e[0] == '0');
+    }();
+    const sd_layer& r2 = blk.res2[0];
+    const bool chain = chain_ok && dt == SD_DT_F16 && w->res2_scale >= 2 &&
+                       sd_res2net_chain_supported(T, chunk, w->res2_scale - 1, r2.taps, r2.dil);
     {
       sd_conv_args a = conv_of(blk.tdnn1, xin, dt, ldin, colin, b.r, dt, C, 0, M, T, SD_ACT_RELU);
-      a.tee = b.s0; a.ldt = chunk; a.tee_lo = chunk; a.tee_hi = 2 * chunk;
+      if (!chain) { a.tee = b.s0; a.ldt = chunk; a.tee_lo = chunk; a.tee_hi = 2 * chunk; }
       SD_TRY(run_conv(a, stream));
     }
-    // Res2Net chain: y_j = TDNN_j(c_j + y_{j-1}), written over chunk j of r
-    for (int j = 1; j < w->res2_scale; ++j) {
-      void* src = (j & 1) ? b.s0 : b.s1;
-      void* dst = (j & 1) ? b.s1 : b.s0;
-      sd_conv_args a = conv_of(blk.res2[j - 1], src, dt, chunk, 0, b.r, dt, C, j * chunk, M, T, SD_ACT_RELU);
-      if (j + 1 < w->res2_scale) {
-        a.tee = dst; a.ldt = chunk; a.tee_lo = 0; a.tee_hi = chunk;
-        a.tee_add = b.r; a.ld_ta = C; a.ta_col0 = (j + 1) * chunk;
+    if (chain) {
+      SD_TRY(sd_res2net_chain_f16(b.r, C, B, T, blk.res2, w->res2_scale - 1, stream));
+    } else {
+      for (int j = 1; j < w->res2_scale; ++j) {
+        void* src = (j & 1) ? b.s0 : b.s1;
+        void* dst = (j & 1) ? b.s1 : b.s0;
+        sd_conv_args a = conv_of(blk.res2[j - 1], src, dt, chunk, 0, b.r, dt, C, j * chunk, M, T, SD_ACT_RELU);
+        if (j + 1 < w->res2_scale) {
+          a.tee = dst; a.ldt = chunk; a.tee_lo = 0; a.tee_hi = chunk;
+          a.tee_add = b.r; a.ld_ta = C; a.ta_col0 = (j + 1) * chunk;
+        }
+        SD_TRY(run_conv(a, stream));
       }
-      SD_TRY(run_conv(a, stream));
     }
     // tdnn2; the SE squeeze (mean over T) comes out of its epilogue as per-tile column sums where the
     // geometry allows (the Res2Net scratch s0 is dead and holds them), else from a pass over t2

@@ -474,12 +474,7 @@ extern "C" int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int
   hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a.maxbuf, B, (int)0x80808080);
   SD_CHECK_LAUNCH("fill_i32_kernel");
   const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank_logmel_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(fbank_logmel_kernel), (int)lds));
   {
     // algorithmic bytes: waveform read once + log-mel written once (192 320 B per 2 s segment)
     SdProfScope prof(SD_PROF_FBANK, stream, (double)B * ((double)n * 4.0 + (double)T * plan->n_mels * 4.0));

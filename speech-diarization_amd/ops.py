@@ -90,6 +90,30 @@ def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, T: int, *, cin: int, dil:
     return out
 
 
+def res2net_chain_supported(T: int, chunk: int = 128, n: int = 7, taps: int = 3, dil: int = 2) -> bool:
+    return bool(N.load().sd_res2net_chain_supported(T, chunk, n, taps, dil))
+
+
+def res2net_chain(r: torch.Tensor, T: int, layers: list[dict]) -> torch.Tensor:
+    """The Res2Net chain of one SE-Res2Net block in one kernel, IN PLACE on the tdnn1 output r [B*T, ld] (f16):
+    y_1 = TDNN_1(c_1), y_j = TDNN_j(c_j + y_{j-1}); c_j = columns [128 j, 128 j + 128), y_j overwrites c_j.
+    layers[j]: dict(w=packed f16 [128, 3, 128], bias, scale, shift (f32 [128] or None), dil)."""
+    _need_cuda(r)
+    if r.dtype != torch.float16 or r.stride(1) != 1:
+        raise TypeError("r must be f16 with contiguous channels")
+    lib = N.load()
+    arr = (N.sd_layer * len(layers))()
+    for L, d in zip(arr, layers):
+        _need_cuda(d["w"], d.get("bias"), d.get("scale"), d.get("shift"))
+        cout, taps, cin_pad = d["w"].shape
+        L.w, L.bias, L.scale, L.shift = d["w"].data_ptr(), _ptr(d.get("bias")), _ptr(d.get("scale")), _ptr(d.get("shift"))
+        L.cin, L.cin_pad, L.cout, L.taps, L.dil, L.w_dtype = d.get("cin", cin_pad), cin_pad, cout, taps, d["dil"], _dt(d["w"].dtype)
+    B = r.shape[0] // T
+    with torch.cuda.device(r.device):
+        N.check(lib.sd_res2net_chain_f16(r.data_ptr(), r.stride(0), B, T, arr, len(layers), _stream(r)), "sd_res2net_chain_f16")
+    return r
+
+
 def colstat_floats(M: int, cout: int) -> int:
     return int(N.load().sd_colstat_floats(M, cout))
 

@@ -258,3 +258,97 @@ def test_f16_and_f32_engines_give_the_same_clusters(dev):
         labels.append(cluster.relabel_by_first_appearance(cluster.spectral(K, 3)))
     assert np.array_equal(labels[0], labels[1]) and np.array_equal(labels[1], labels[2])
     assert len(set(labels[0].tolist())) == 3
+
+
+# ---- fused Res2Net chain (sd_res2net_chain_f16): one kernel per SE-Res2Net block
+
+def _chain_case(seed, B, T, dil, n=7, C=1024):
+    g = torch.Generator().manual_seed(seed)
+    r = (torch.randn(B * T, C, generator=g) * 0.7).half()
+    layers = []
+    for j in range(n):
+        layers.append(dict(w=(torch.randn(128, 128, 3, generator=g) / np.sqrt(384)).half().float(), bias=torch.randn(128, generator=g) * 0.1,
+                           scale=torch.rand(128, generator=g) + 0.5, shift=torch.randn(128, generator=g) * 0.1, dil=dil))
+    return r, layers
+
+
+def _chain_f64(r, layers, T):
+    """float64 restatement with the path's own f16 roundings of the chain state (y_j and c_{j+1} + y_j)."""
+    r = r.double().clone()
+    n = len(layers)
+    u = r[:, 128:256].clone()
+    for j in range(1, n + 1):
+        L = layers[j - 1]
+        y = torch.relu(_ref_conv_cl(u, L["w"].double(), L["bias"].double(), T, L["dil"])) * L["scale"].double() + L["shift"].double()
+        r[:, 128 * j:128 * j + 128] = y.half().double()
+        if j < n:
+            u = (y + r[:, 128 * (j + 1):128 * (j + 2)]).half().double()
+    return r
+
+
+@pytest.mark.parametrize("B,T,dil,n", [(5, 201, 2, 7), (3, 201, 3, 7), (4, 201, 4, 7), (6, 101, 2, 7), (2, 61, 3, 7), (3, 212, 4, 7),
+                                       (2, 16, 2, 7), (1, 5, 4, 3), (2, 208, 2, 1)])
+def test_res2net_chain_matches_f64_and_the_unfused_convs(dev, B, T, dil, n):
+    from speech_diarization_amd import ops
+    assert ops.res2net_chain_supported(T, 128, n, 3, dil)
+    r, layers = _chain_case(B * 1000 + T + dil, B, T, dil, n)
+    ref = _chain_f64(r, layers, T)
+    dl = [dict(w=ops.pack_weight(L["w"], dev, torch.float16), bias=L["bias"].to(dev), scale=L["scale"].to(dev), shift=L["shift"].to(dev), dil=dil)
+          for L in layers]
+    got = r.to(dev).clone()
+    ops.res2net_chain(got, T, dl)
+    torch.cuda.synchronize()
+    got = got.cpu().double()
+    assert torch.equal(got[:, :128], r[:, :128].double())                           # chunk 0 untouched
+    if 128 * (n + 1) < r.shape[1]:
+        assert torch.equal(got[:, 128 * (n + 1):], r[:, 128 * (n + 1):].double())   # chunks past the chain untouched
+    scale = ref[:, 128:128 * (n + 1)].abs().max().item()
+    err = (got - ref)[:, 128:128 * (n + 1)].abs().max().item()
+    # one f16 ulp of a chain-state rounding can flip (the MFMA sums in another order than float64) and then propagates
+    assert err < 4e-3 * scale, (err, scale)
+    # the unfused path: the same operators launched one by one (tee epilogue), same roundings -> same values to f16 rounding flips
+    un = r.to(dev).clone()
+    s0 = un[:, 128:256].clone()
+    s1 = torch.empty_like(s0)
+    for j in range(1, n + 1):
+        src, dst = (s0, s1) if j & 1 else (s1, s0)
+        L = dl[j - 1]
+        kw = dict(cin=128, dil=dil, bias=L["bias"], act="relu", scale=L["scale"], shift=L["shift"], out=un, o_col0=128 * j)
+        if j < n:
+            kw.update(tee=dst, tee_lo=0, tee_hi=128, tee_add=un, ta_col0=128 * (j + 1))
+        ops.conv1d_cl(src, L["w"], T, **kw)
+    torch.cuda.synchronize()
+    d = (un.cpu().double() - got)[:, 128:128 * (n + 1)].abs()
+    assert d.max().item() < 4e-3 * scale and (d > 0).double().mean().item() < 0.05, (d.max().item(), (d > 0).double().mean().item())
+
+
+def test_res2net_chain_refuses_what_it_does_not_cover(dev):
+    from speech_diarization_amd import _native, ops
+    assert not ops.res2net_chain_supported(213, 128, 7, 3, 2)      # three [T][128] f16 buffers no longer fit the LDS
+    assert not ops.res2net_chain_supported(201, 64, 7, 3, 2)
+    assert not ops.res2net_chain_supported(201, 128, 8, 3, 2)
+    assert not ops.res2net_chain_supported(201, 128, 7, 5, 2)
+    assert not ops.res2net_chain_supported(3, 128, 7, 3, 4)        # reflect padding needs dilation < T
+    r, layers = _chain_case(1, 2, 626, 2)
+    dl = [dict(w=ops.pack_weight(L["w"], dev, torch.float16), bias=L["bias"].to(dev), scale=L["scale"].to(dev), shift=L["shift"].to(dev), dil=2)
+          for L in layers]
+    before = r.to(dev)
+    work = before.clone()
+    with pytest.raises(_native.SdError, match="needs 1..7 convs"):
+        ops.res2net_chain(work, 626, dl)
+    assert torch.equal(work, before)                               # nothing was launched
+
+
+def test_ecapa_f16_fused_and_unfused_res2net_agree(dev, monkeypatch):
+    """The engine result with the chain kernel against the float64 oracle is covered by the full-geometry tests; here: a
+    6 s segment (T = 601) takes the per-conv path and 2 s segments the fused one, both within the f16 bar."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    eng = EmbeddingEngine(sd, dev, precision="f16")
+    for n in (32000, 96000):
+        wav = synth.synthetic_segments(3, 2, n)
+        e = eng.embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+        ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
+        assert _cos_dist(e, ref).max() < 1e-5
