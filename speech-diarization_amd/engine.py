@@ -153,22 +153,30 @@ class EmbeddingEngine:
         self.precision = precision
         self._forward = self._lib.sd_ecapa_forward_f16 if precision == "f16" else self._lib.sd_ecapa_forward_f32
         self._ws = None
-        self._ws_key = None
+        self._ws_frozen = False
 
-    # -- workspace: feats + fbank scratch + ECAPA activations, grown on demand
+    # -- workspace: feats + fbank scratch + ECAPA activations, three flat buffers that only ever grow (keyed by
+    # capacity, not by the exact (B, n): the reference's callers send batches whose padded length changes every call
+    # [REF anti_stick_diarize.py:163-166], and re-allocating ~10 MB per segment per call was a measurable part of it)
     def _workspace(self, B: int, n: int):
-        key = (B, n)
-        if self._ws_key is not None and self._ws_key[0] >= B and self._ws_key[1] == n:
-            return self._ws
         T = FbankPlan.num_frames(n)
         n_mels = self.weights.cfg.input_size
-        feats = torch.empty((B * T, n_mels), dtype=torch.float32, device=self.device)
-        fb_bytes = self.plan.workspace_bytes(B, n)
-        fb_ws = torch.empty((max(fb_bytes, 256),), dtype=torch.uint8, device=self.device)
-        ec_bytes = int(self._lib.sd_ecapa_workspace_bytes(C.byref(self.weights.struct), B, T))
-        ec_ws = torch.empty((ec_bytes,), dtype=torch.uint8, device=self.device)
-        self._ws, self._ws_key = (feats, fb_ws, ec_ws), key
+        need = (B * T * n_mels * 4, max(self.plan.workspace_bytes(B, n), 256),
+                int(self._lib.sd_ecapa_workspace_bytes(C.byref(self.weights.struct), B, T)))
+        if self._ws is None:
+            self._ws = [None, None, None]
+        for i, nbytes in enumerate(need):
+            if self._ws[i] is None or self._ws[i].numel() < nbytes:
+                if self._ws_frozen:
+                    raise RuntimeError("this engine's workspace is referenced by a captured hipGraph (StreamingEmbedder); "
+                                       "use a separate EmbeddingEngine for larger batches")
+                self._ws[i] = None                     # release before growing
+                self._ws[i] = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def freeze_workspace(self) -> None:
+        """After a hipGraph capture of `embed`: the captured launches hold the workspace pointers, so it may no longer move."""
+        self._ws_frozen = True
 
     def embed(self, wav: torch.Tensor) -> torch.Tensor:
         """wav: f32 [B, n] on this engine's device -> f32 [B, dim] on the device (async on the current stream)."""
@@ -192,7 +200,7 @@ class EmbeddingEngine:
             for lo in range(0, B, mb):
                 nb = min(mb, B - lo)
                 x = wav[lo:lo + nb]
-                N.check(self._lib.sd_fbank_f32(self.plan.handle, x.data_ptr(), nb, n, 1, feats.data_ptr(), feats.shape[1],
+                N.check(self._lib.sd_fbank_f32(self.plan.handle, x.data_ptr(), nb, n, 1, feats.data_ptr(), self.weights.cfg.input_size,
                                                fb_ws.data_ptr(), fb_ws.numel(), stream), "sd_fbank_f32")
                 N.check(self._forward(W, feats.data_ptr(), nb, T, out[lo:lo + nb].data_ptr(),
                                       ec_ws.data_ptr(), ec_ws.numel(), stream), f"sd_ecapa_forward_{self.precision}")

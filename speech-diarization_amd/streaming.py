@@ -46,6 +46,7 @@ class StreamingEmbedder:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._static_out = self.engine.embed(self._static_in)
+        self.engine.freeze_workspace()
 
     def push(self, chunk: torch.Tensor) -> torch.Tensor:
         """chunk: f32 [channels, hop samples] (device or host) -> embeddings [channels, 192] of the updated windows."""
