@@ -24,6 +24,9 @@
  *   sd_l2norm_rows_f32    replaces  X / (||X|| + 1e-8) [REF anti_stick_diarize.py:176,430]
  *   sd_adjacent_cosine_f32 replaces the einsum pair cosine [REF anti_stick_diarize.py:102-104]
  *   sd_sim_argmax_f32     replaces  argmax(W @ C.T) [REF anti_stick_diarize.py:433-434]
+ *   sd_topk_mean_std_f32, sd_asnorm_combine_f32   the top-k cohort statistics and combination of
+ *                                   asnorm_scores [REF diar_diag.py:196-208] (its cosine products run on sd_conv1d_cl_f32)
+ *   sd_viterbi_f32        replaces  viterbi_hmm [REF diar_diag.py:231-247]
  *
  * Conventions: every pointer named *_dev / documented "device" is a HIP device
  * pointer; all functions are asynchronous on `stream`, never allocate and never
@@ -280,6 +283,23 @@ int sd_adjacent_cosine_f32(const float* x, int ldx, int N, int D, float eps, flo
 /* best[i] = argmax_k <w[i], c[k]> (first max wins, numpy argmax), score[i] = max */
 int sd_sim_argmax_f32(const float* w, int ldw, int N, int D, const float* c, int ldc, int K,
                       int32_t* best, float* score, sd_stream_t stream);
+
+/* ------------------------------------------- score normalisation / smoothing */
+
+/* Per row of x [rows][ld] (n valid columns): mean and population std of its k largest values
+ * (np.sort(x, axis=1)[:, -k:].mean / .std of `asnorm_scores` [REF diar_diag.py:201-204]; k is clipped to n).
+ * out [rows][2] = [mean | std].  Exact selection (radix select), f32 arithmetic. */
+int sd_topk_mean_std_f32(const float* x, int ld, int rows, int n, int k, float* out, sd_stream_t stream);
+/* out[i][j] = 0.5 * ((raw[i][j] - qstat[i][0]) / (qstat[i][1] + 1e-6) + (raw[i][j] - rstat[j][0]) / (rstat[j][1] + 1e-6))
+ * [REF diar_diag.py:205-208]; raw [nq][ld], out [nq][ldo]. */
+int sd_asnorm_combine_f32(const float* raw, int ld, int nq, int nr, const float* qstat, const float* rstat,
+                          float* out, int ldo, sd_stream_t stream);
+/* Most likely state path through scores [T][ld] (K <= 64 states) under a transition matrix with log_stay on the
+ * diagonal and log_move elsewhere, f32 arithmetic and first-maximum tie-breaking as `viterbi_hmm`
+ * [REF diar_diag.py:231-247].  ws: sd_viterbi_workspace_bytes(T, K) (back pointers); path: int32 [T]. */
+size_t sd_viterbi_workspace_bytes(int T, int K);
+int sd_viterbi_f32(const float* scores, int ld, int T, int K, float log_stay, float log_move,
+                   void* ws, size_t ws_bytes, int32_t* path, sd_stream_t stream);
 
 #ifdef __cplusplus
 }

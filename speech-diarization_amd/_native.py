@@ -130,6 +130,10 @@ PROTOTYPES = {
     "sd_cosine_affinity_rows_split16": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_adjacent_cosine_f32": (_I, [_P, _I, _I, _I, _F, _P, _P]),
     "sd_sim_argmax_f32": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
+    "sd_topk_mean_std_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "sd_asnorm_combine_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "sd_viterbi_workspace_bytes": (_Z, [_I, _I]),
+    "sd_viterbi_f32": (_I, [_P, _I, _I, _I, _F, _F, _P, _Z, _P, _P]),
 }
 
 _lib = None

@@ -20,9 +20,17 @@ def _l2n(x: np.ndarray) -> np.ndarray:
     return x / (np.linalg.norm(x, axis=-1, keepdims=True) + 1e-9)
 
 
-def asnorm_scores(query_embs: np.ndarray, ref_centers: np.ndarray, cohort_embs: np.ndarray, topk: int = 200) -> np.ndarray:
+def asnorm_scores(query_embs: np.ndarray, ref_centers: np.ndarray, cohort_embs: np.ndarray, topk: int = 200, device=None) -> np.ndarray:
     """Adaptive symmetric score normalisation: cosine scores z-normalised against the top-k cohort
-    scores of the query and of the reference, averaged [REF diar_diag.py:196-208]."""
+    scores of the query and of the reference, averaged [REF diar_diag.py:196-208].
+    `device="cuda"`: the cohort products, the top-k statistics and the combination run on the GPU
+    (`ops.asnorm_scores`, f32); default: the reference's numpy arithmetic in the input dtype."""
+    if device is not None:
+        import torch
+        from . import ops
+        dev = torch.device(device)
+        t = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev) for a in (query_embs, ref_centers, cohort_embs)]
+        return ops.asnorm_scores(t[0], t[1], t[2], topk).cpu().numpy()
     Q, R, Cc = _l2n(np.asarray(query_embs)), _l2n(np.asarray(ref_centers)), _l2n(np.asarray(cohort_embs))
     raw = Q @ R.T
     k = min(topk, Cc.shape[0])
@@ -47,9 +55,15 @@ def cluster_embeddings(embs: np.ndarray, method: str = "hdbscan", cos_thr: float
     raise ValueError("method must be 'hdbscan' or 'agglo'")
 
 
-def viterbi_hmm(scores: np.ndarray, alpha: float = 0.995) -> np.ndarray:
+def viterbi_hmm(scores: np.ndarray, alpha: float = 0.995, device=None) -> np.ndarray:
     """Most likely speaker path through per-window log-scores [T, K] under a sticky transition matrix
-    (stay alpha, move (1-alpha)/(K-1)), float32 arithmetic as in [REF diar_diag.py:231-247]."""
+    (stay alpha, move (1-alpha)/(K-1)), float32 arithmetic as in [REF diar_diag.py:231-247].
+    `device="cuda"`: the same recurrence in one wave on the GPU (`ops.viterbi`, K <= 64, f32 scores)."""
+    if device is not None:
+        import torch
+        from . import ops
+        sc = torch.from_numpy(np.ascontiguousarray(scores, dtype=np.float32)).to(torch.device(device))
+        return ops.viterbi(sc, alpha).cpu().numpy()
     scores = np.asarray(scores)
     T, K = scores.shape
     eps = 1e-8

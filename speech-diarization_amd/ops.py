@@ -248,3 +248,61 @@ def sim_argmax(w: torch.Tensor, c: torch.Tensor):
         N.check(N.load().sd_sim_argmax_f32(w.data_ptr(), d, n, d, c.data_ptr(), d, k, best.data_ptr(), score.data_ptr(), _stream(w)),
                 "sd_sim_argmax_f32")
     return best, score
+
+
+def topk_mean_std(x: torch.Tensor, k: int) -> torch.Tensor:
+    """[rows, n] f32 -> [rows, 2] = mean and population std of each row's k largest values (k clipped to n)."""
+    _need_cuda(x)
+    x = x.float()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, n = x.shape
+    out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.load().sd_topk_mean_std_f32(x.data_ptr(), x.stride(0), rows, n, int(k), out.data_ptr(), _stream(x)), "sd_topk_mean_std_f32")
+    return out
+
+
+def asnorm_scores(query: torch.Tensor, centers: torch.Tensor, cohort: torch.Tensor, topk: int = 200) -> torch.Tensor:
+    """`asnorm_scores` [REF diar_diag.py:196-208] on the device: rows scaled by 1 / (norm + 1e-9), the three cosine
+    products on the f32 matrix cores (the operator behind the 1x1 convs, T = 1), top-k cohort statistics per row,
+    z-normalisation against the query's and the centre's cohort scores, averaged.  f32 [nq, nr]."""
+    _need_cuda(query, centers, cohort)
+    lib = N.load()
+    qn, rn, cn = (l2norm_rows(t, eps_add=1e-9) for t in (query, centers, cohort))
+    d = qn.shape[1]
+
+    def product(a, b):                                   # a @ b.T with b as the packed "weights" [rows, 1, d_pad]
+        wp = pack_weight(b.unsqueeze(2), b.device, torch.float32) if d % 32 else b.reshape(b.shape[0], 1, d).contiguous()
+        return conv1d_cl(a, wp, 1, cin=d)
+
+    raw = product(qn, rn)
+    k = min(int(topk), cn.shape[0])
+    qstat = topk_mean_std(product(qn, cn), k)
+    rstat = topk_mean_std(product(rn, cn), k)
+    out = torch.empty_like(raw)
+    with torch.cuda.device(raw.device):
+        N.check(lib.sd_asnorm_combine_f32(raw.data_ptr(), raw.stride(0), raw.shape[0], raw.shape[1], qstat.data_ptr(), rstat.data_ptr(),
+                                          out.data_ptr(), out.stride(0), _stream(raw)), "sd_asnorm_combine_f32")
+    return out
+
+
+def viterbi(scores: torch.Tensor, alpha: float = 0.995) -> torch.Tensor:
+    """`viterbi_hmm` [REF diar_diag.py:231-247] on the device: scores f32 [T, K <= 64] -> int32 path [T]; the two
+    transition log-probabilities are formed as the reference forms them (float64 log, rounded to f32)."""
+    _need_cuda(scores)
+    scores = scores.contiguous().float()
+    T, K = scores.shape
+    path = torch.empty((T,), dtype=torch.int32, device=scores.device)
+    if T == 0:
+        return path
+    eps = 1e-8
+    log_move = float(np.float32(np.log((1 - alpha) / (K - 1) + eps))) if K > 1 else 0.0
+    log_stay = float(np.float32(np.log(alpha + eps)))
+    lib = N.load()
+    with torch.cuda.device(scores.device):
+        nbytes = int(lib.sd_viterbi_workspace_bytes(T, K))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=scores.device)
+        N.check(lib.sd_viterbi_f32(scores.data_ptr(), scores.stride(0), T, K, C.c_float(log_stay), C.c_float(log_move), ws.data_ptr(), nbytes,
+                                   path.data_ptr(), _stream(scores)), "sd_viterbi_f32")
+    return path

@@ -195,3 +195,58 @@ def test_adjacent_cosine_and_argmax(dev):
     ref_best, ref_sim = assign_windows_ref(e.astype(np.float64), c.astype(np.float64))
     assert np.array_equal(best.cpu().numpy(), ref_best)
     assert np.abs(score.cpu().numpy() - ref_sim.max(1)).max() < 1e-6
+
+
+# ---- N3: AS-norm and Viterbi on the device [REF diar_diag.py:196-208, 231-247]
+
+def test_topk_mean_std_matches_numpy(dev):
+    from speech_diarization_amd import ops
+    rng = np.random.default_rng(3)
+    for rows, n, k in [(7, 64, 20), (3, 1000, 200), (5, 10000, 200), (2, 50, 200), (4, 257, 1), (1, 300, 300)]:
+        x = rng.standard_normal((rows, n)).astype(np.float32)
+        x[0, : n // 3] = x[0, 0]                       # many ties, some of them at the k-th value
+        if rows > 1:
+            x[1] = 0.25                                # a constant row: std exactly 0
+        got = ops.topk_mean_std(torch.from_numpy(x).to(dev), k).cpu().numpy()
+        kk = min(k, n)
+        top = np.sort(x.astype(np.float64), axis=1)[:, -kk:]
+        assert np.allclose(got[:, 0], top.mean(1), atol=2e-6), (rows, n, k)
+        assert np.allclose(got[:, 1], top.std(1), atol=2e-6), (rows, n, k)
+    xs = torch.randn(6, 300, device=dev)
+    padded = torch.full((6, 512), 99.0, device=dev)    # row stride > n: the padding must not be read
+    padded[:, :300] = xs
+    assert torch.equal(ops.topk_mean_std(padded[:, :300], 50), ops.topk_mean_std(xs, 50))
+
+
+def test_asnorm_scores_gpu_matches_reference_goldens_and_host(dev, golden_dir):
+    import json, os
+    from speech_diarization_amd import diar_diag as dd
+    with open(os.path.join(golden_dir, "diar_diag.json")) as f:
+        cases = json.load(f)
+    for case in cases:
+        e, cents, cohort = (np.asarray(case[k], dtype=np.float64) for k in ("embs", "centers", "cohort"))
+        got = dd.asnorm_scores(e, cents, cohort, topk=20, device=dev)
+        assert got.dtype == np.float32
+        assert np.abs(got - np.asarray(case["asnorm"])).max() < 2e-4          # reference output (float64) vs the f32 device path
+    rng = np.random.default_rng(9)
+    q, c, coh = (rng.standard_normal((n, 192)).astype(np.float32) for n in (500, 6, 3000))
+    host = dd.asnorm_scores(q.astype(np.float64), c.astype(np.float64), coh.astype(np.float64), topk=200)
+    assert np.abs(dd.asnorm_scores(q, c, coh, topk=200, device=dev) - host).max() < 5e-4
+    assert dd.asnorm_scores(q, c, coh[:50], topk=200, device=dev).shape == (500, 6)   # cohort smaller than top-k
+
+
+def test_viterbi_gpu_path_equals_the_reference_path(dev, golden_dir):
+    import json, os
+    from speech_diarization_amd import diar_diag as dd
+    with open(os.path.join(golden_dir, "diar_diag.json")) as f:
+        cases = json.load(f)
+    for case in cases:
+        scores = np.asarray(case["scores"], dtype=np.float32)
+        assert dd.viterbi_hmm(scores, alpha=0.9, device=dev).tolist() == case["viterbi"]
+        assert dd.viterbi_hmm(scores, device=dev).tolist() == case["viterbi_sticky"]
+    rng = np.random.default_rng(4)
+    for T, K, alpha in [(1, 3, 0.9), (2, 2, 0.995), (129, 8, 0.9), (1000, 16, 0.995), (36000, 8, 0.995), (300, 1, 0.9), (257, 64, 0.9)]:
+        sc = rng.standard_normal((T, K)).astype(np.float32)
+        sc[::7] = np.round(sc[::7])                    # exact ties between states: first maximum must win
+        got = dd.viterbi_hmm(sc, alpha, device=dev)
+        assert got.dtype == np.int32 and got.tolist() == dd.viterbi_hmm(sc, alpha).tolist(), (T, K, alpha)
