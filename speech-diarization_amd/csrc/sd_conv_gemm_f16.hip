@@ -254,6 +254,7 @@ __device__ __forceinline__ float sd_row16_sum(float v) {
 // column-statistics unit) and channels [col0, col0 + 64)
 template <typename TO, typename ACC>
 __device__ __forceinline__ void sd_direct_epilogue(const sd_conv_args& p, ACC (&acc)[8][4], int row0, int col0, int fr, int fq) {
+  if (row0 >= p.M) return;                         // the half of the last tile that starts past the last row: no rows, no statistics unit
   const float lo = p.act == SD_ACT_RELU ? 0.f : -INFINITY;
   TO* const Y = static_cast<TO*>(p.y) + p.o_col0;
   const int rb = p.T - row0 % p.T;                 // first unit-relative row of the next segment (>= 128: none)

@@ -352,3 +352,51 @@ def test_ecapa_f16_fused_and_unfused_res2net_agree(dev, monkeypatch):
         e = eng.embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
         ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
         assert _cos_dist(e, ref).max() < 1e-5
+
+
+def test_fused_f16_pooling_bounds_the_cancellation(dev):
+    """asp_attend_pool_f16_kernel forms the weighted variance as E_w[h^2] - mu^2 (the oracle: sum a (h - mu)^2).  Known-answer
+    case with |mu| >> sigma: h = 50 + 0.01 noise.  f32 accumulation of f16 products keeps the difference to ~50^2 * 2^-22 / sigma."""
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, T, Cc, att = 3, 201, 512, 128
+    a1 = torch.tanh(torch.randn(B * T, att, generator=g)).half()
+    wc = (torch.randn(Cc, att, 1, generator=g) / 4).half()
+    for mean, sigma in ((50.0, 0.01), (8.0, 0.05), (-20.0, 0.02)):
+        h = (mean + sigma * torch.randn(B * T, Cc, generator=g)).half()          # f16 spacing at 50 is 0.03: few distinct values
+        got = ops.asp_attend_pool(a1.to(dev), ops.pack_weight(wc.float(), dev, torch.float16), h.to(dev), B, T).cpu().double()
+        a = torch.softmax((a1.double() @ wc[:, :, 0].double().T).view(B, T, Cc), dim=1)
+        hr = h.double().view(B, T, Cc)
+        mu = (a * hr).sum(1)
+        sd = torch.sqrt(((a * (hr - mu[:, None]) ** 2).sum(1)).clamp_min(1e-12))
+        assert (got[:, :Cc] - mu).abs().max() < 2e-5 * max(1.0, abs(mean))
+        # absolute error of the variance ~ mean^2 * 2^-21 -> of the std ~ that / (2 sd)
+        bound = (mean * mean * 2.0 ** -21) / (2 * sd.min().item()) + 2e-4
+        assert (got[:, Cc:] - sd).abs().max() < bound, (mean, sigma, (got[:, Cc:] - sd).abs().max().item(), bound)
+        assert torch.isfinite(got).all() and (got[:, Cc:] >= 0).all()
+
+
+def test_identical_clusters_at_full_geometry(dev):
+    """north_star: 'identical cluster assignments on the same inputs' — f16 path, f32 path and the CPU oracle at the
+    full C = 1024 geometry (the width-128 twin of this test runs more windows)."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import cluster, ops, synth
+    from speech_diarization_amd.diarization_baseline import gather_windows, speech_windows
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    conv = synth.synthetic_conversation(30.0, 3, seed=2)
+    speech = [(s, e) for s, e, _ in conv.turns]
+    starts, _, _ = speech_windows(speech, len(conv.wav), 16000, 2.0, 0.5)
+    wav = gather_windows(conv.wav, starts, 32000)
+    embs = [EmbeddingEngine(sd, dev, precision="f16").embed(torch.from_numpy(wav).to(dev)).cpu().numpy(),
+            EmbeddingEngine(sd, dev, precision="f32").embed(torch.from_numpy(wav).to(dev)).cpu().numpy(),
+            pipeline_ref.encode_batch_ref(sd, wav, torch.float32)]
+    labels = []
+    for emb in embs:
+        K = ops.cosine_affinity(torch.from_numpy(cluster.center(emb).astype(np.float32)).to(dev)).cpu().numpy()
+        labels.append((cluster.relabel_by_first_appearance(cluster.spectral(K, 3)),
+                       cluster.relabel_by_first_appearance(cluster.ahc_cosine(K, 0.3))))
+    for lab in labels[1:]:
+        assert np.array_equal(lab[0], labels[0][0]) and np.array_equal(lab[1], labels[0][1])
+    assert len(set(labels[0][0].tolist())) == 3
+    assert _cos_dist(embs[0], embs[2]).max() < 1e-3 and _cos_dist(embs[1], embs[2]).max() < 1e-5

@@ -120,3 +120,39 @@ def test_full_diarize_pipeline_runs_on_gpu(small_encoder):
         out = asd.diarize(conv.wav, 16000, scd_thr=3.0, cluster_cos=0.2, clusterer=clusterer)
         assert out and all(isinstance(s, asd.Segment) and s.spk is not None and s.end > s.start for s in out), clusterer
     assert asd.diarize(np.zeros(32000, np.float32), 16000) == []                     # no speech -> []
+
+
+def test_first_encoder_call_from_racing_worker_threads(tmp_path):
+    """A fresh process whose FIRST launches of every kernel come from two worker threads at once (the reference's web UI
+    calls the pipeline from a worker thread [REF diarize-webui.py:142-160]): the per-device one-time kernel attributes
+    (dynamic LDS > 64 KB) must be set exactly once, under a lock, before either launch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, threading
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from speech_diarization_amd import synth
+from speech_diarization_amd.engine import EmbeddingEngine
+dev = torch.device("cuda", 0)
+sd = synth.make_ecapa_state_dict(1234, synth.EcapaConfig.small(256))
+engines = [EmbeddingEngine(sd, dev, precision=p) for p in ("f32", "f16")]
+wav = torch.from_numpy(synth.synthetic_segments(3, 8, 32000)).to(dev)
+out, err = {{}}, []
+def work(i):
+    try:
+        with torch.cuda.device(dev):
+            out[i] = engines[i].embed(wav).cpu().numpy()
+    except Exception as e:
+        err.append(repr(e))
+ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not err, err
+again = [e.embed(wav).cpu().numpy() for e in engines]
+assert np.array_equal(out[0], again[0]) and np.array_equal(out[1], again[1])
+print("ok")
+"""
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stderr[-2000:]
