@@ -316,6 +316,266 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const FbankArgs p)
 #endif
 }
 
+// ==========================================================================================
+// Version 2 of the main kernel: the same folded DFT, on the f16 matrix cores at f32 accuracy.
+//
+// The exact-f32 MFMA runs at 1/16 of the f16 rate, and round 1's kernel was bound by it (ideal MFMA time 1.4 ms of its
+// 3.0 ms per 5000 segments).  Here every f32 operand is split into two halves, v = hi + lo with hi = f16(v) and
+// lo = f16(v - hi), and a product is  hi.hi + hi.lo + lo.hi  on v_mfma_f32_32x32x16_f16 with f32 accumulation: the
+// dropped lo.lo term and the representation error are 2^-22 relative per product, i.e. f32-level, for three MFMAs
+// that do sixteen times the work of an f32 one (the scheme of the split-precision affinity, sd_pool.hip).  The samples
+// are scaled by 2^10 when staged (folded sums <= 2048 < f16 max) so that the LOW halves stay clear of the f16
+// subnormals down to signals of 1e-7 full scale (what matters for a quiet segment is the error relative to ITS level:
+// unscaled, a -100 dBFS segment would keep only ~12 bits); the power spectrum takes 2^-20 back, exactly.
+//   * DFT: 6 MFMAs per (32-bin tile, 16 k): 546 of 32 cycles per wave tile instead of 1428 of 64.
+//   * mel: |X|^2 goes from the DFT accumulators straight into the next MFMA as its B operand (the accumulator rows are
+//     the next product's k: no lane movement), split into two bf16 halves (f32 exponent range), against mel weights
+//     split the same way: 3 products on v_mfma_f32_32x32x16_bf16, 2^-16 relative (the log needs 2e-4).
+//   * loop order: k outer, bin tiles inner, in two passes (bin tiles 0-3, then 4-6) so that a pass's accumulators
+//     (128 registers) stay resident and the folded, split signal fragments are built once per pass and k step, not per
+//     bin tile; the basis fragments of a (pass, k step) are one contiguous 16 / 12 KB block that the four waves share
+//     through a double-buffered LDS stage filled by LDS-DMA.
+//   * LDS sample image: sample i of a span sits at word i + 4 (i / 160): frame starts (stride 164 words) and every
+//     aligned group of 4 samples stay 16-byte aligned, and the 16 frames of a ds_read_b128 lane group fall on 16
+//     distinct bank slots (41 j mod 16 = 9 j).
+constexpr int V2_XS_W = 5952;                       // per-wave sample image, floats (two spans + skew + alignment slack)
+constexpr int V2_STAGE_BYTES = 16 * 1024;           // basis fragments of one (pass, k step): 4 tiles x 4 kinds x 1 KB
+constexpr int V2_KSTEPS = 13;                       // 208 / 16
+constexpr int V2_LDS_BYTES = WAVES * V2_XS_W * 4 + 2 * V2_STAGE_BYTES;
+static_assert(WAVES * FT * MELP * 4 <= WAVES * V2_XS_W * 4, "the log-mel staging reuses the sample image");
+constexpr size_t V2_BASIS_BYTES = (size_t)V2_KSTEPS * NBT * 4 * 1024;        // 364 KB
+constexpr size_t V2_MELW_BYTES = (size_t)NBT * 2 * 3 * 2 * 1024;             // 84 KB
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+
+struct Fbank2Args {
+  const float* wav; int B; int n; int T;
+  const _Float16* basis;   // [pass][k step][tile in pass][Chi | Clo | Shi | Slo][64 lanes][8]
+  const __bf16* melw;      // [bin tile][k half][mel tile][W1 | W2][64 lanes][8]
+  int n_mels; int pad_mode; int log_mode; float log_eps;
+  float* out; int ld_out;
+  int* maxbuf;
+  int flat;
+};
+
+#define FB2_GLDS16(gptr, lptr)                                                             \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),  \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// one pass over NTILE bin tiles starting at tile Q0: DFT into acc, then their power spectra into the mel accumulators
+template <int NTILE, int Q0>
+__device__ __forceinline__ void fbank2_pass(const Fbank2Args& p, const float* xs, int base, char* stage, int lane, int wid,
+                                            f32x16 (&mel)[3]) {
+  const int j = lane & 31, h = lane >> 5;
+  (void)j;
+  f32x16 re[NTILE], im[NTILE];
+#pragma unroll
+  for (int q = 0; q < NTILE; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { re[q][r] = 0.f; im[q][r] = 0.f; }
+  constexpr int STAGE = NTILE * 4 * 1024;                                     // bytes of one (pass, k step) block
+  const char* const gsrc = reinterpret_cast<const char*>(p.basis) + (Q0 == 0 ? 0 : (size_t)V2_KSTEPS * 4 * 4 * 1024);
+  auto dma = [&](int s, int buf) {                                            // wave w moves pieces w, w + 4, ...
+#pragma unroll
+    for (int pc = 0; pc < NTILE; ++pc) {
+      const int piece = pc * WAVES + wid;
+      FB2_GLDS16(gsrc + (size_t)s * STAGE + piece * 1024 + lane * 16, stage + buf * V2_STAGE_BYTES + piece * 1024);
+    }
+  };
+  dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < V2_KSTEPS; ++s) {
+    if (s + 1 < V2_KSTEPS) dma(s + 1, (s + 1) & 1);
+    // ---- folded signal of this lane: k = 16 s + 8 h + e, e < 8:  a = x[k] + x[400 - k],  d = x[k] - x[400 - k]
+    const int g = 2 * s + h;                                                  // group of 8 k
+    const float* fw = xs + base + 8 * g + 4 * (g / 20);                       // x[8 g ..]: 8 g and 8 g + 7 share a block of 160
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(fw), f1 = *reinterpret_cast<const f32x4*>(fw + 4);
+    // x[400 - 8 g - e]: aligned blocks starting at sample 392 - 8 g, 396 - 8 g, 400 - 8 g
+    auto blk = [&](int i0) { return *reinterpret_cast<const f32x4*>(xs + base + i0 + 4 * (i0 / HOP)); };
+    const int i0 = 392 - 8 * g;
+    const f32x4 b0 = blk(i0), b1 = blk(i0 + 4), b2 = blk(i0 + 8);
+    float fwd[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+    float bwd[8] = {b2[0], b1[3], b1[2], b1[1], b1[0], b0[3], b0[2], b0[1]};
+    if (g == 0) bwd[0] = 0.f;                                                 // x[400] := 0
+    h8v ahi, alo, dhi, dlo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = fwd[e] + bwd[e], d = fwd[e] - bwd[e];                 // (samples were scaled by 2^10 when staged)
+      ahi[e] = (_Float16)a; alo[e] = (_Float16)(a - (float)ahi[e]);
+      dhi[e] = (_Float16)d; dlo[e] = (_Float16)(d - (float)dhi[e]);
+    }
+    const char* st = stage + (s & 1) * V2_STAGE_BYTES + lane * 16;
+#pragma unroll
+    for (int q = 0; q < NTILE; ++q) {
+      const h8v chi = *reinterpret_cast<const h8v*>(st + (q * 4 + 0) * 1024);
+      const h8v clo = *reinterpret_cast<const h8v*>(st + (q * 4 + 1) * 1024);
+      const h8v shi = *reinterpret_cast<const h8v*>(st + (q * 4 + 2) * 1024);
+      const h8v slo = *reinterpret_cast<const h8v*>(st + (q * 4 + 3) * 1024);
+      re[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(chi, ahi, re[q], 0, 0, 0);
+      im[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(shi, dhi, im[q], 0, 0, 0);
+      re[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(chi, alo, re[q], 0, 0, 0);
+      im[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(shi, dlo, im[q], 0, 0, 0);
+      re[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(clo, ahi, re[q], 0, 0, 0);
+      im[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(slo, dhi, im[q], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // next stage landed
+    __syncthreads();                                                          // ... and everybody is done with this one
+  }
+  // ---- |X|^2 -> mel: accumulator registers 8 s2 .. 8 s2 + 7 are the B fragment of k half s2 (rows = bins = k)
+#pragma unroll
+  for (int q = 0; q < NTILE; ++q) {
+    const __bf16* wq = p.melw + ((size_t)(Q0 + q) * 2 * 3 * 2 * 64 + lane) * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf8v p1, p2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pw = (re[q][8 * s2 + e] * re[q][8 * s2 + e] + im[q][8 * s2 + e] * im[q][8 * s2 + e]) * 0x1p-20f;
+        p1[e] = (__bf16)pw;
+        p2[e] = (__bf16)(pw - (float)p1[e]);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const bf8v w1 = *reinterpret_cast<const bf8v*>(wq + ((size_t)(s2 * 3 + t) * 2 + 0) * 64 * 8);
+        const bf8v w2 = *reinterpret_cast<const bf8v*>(wq + ((size_t)(s2 * 3 + t) * 2 + 1) * 64 * 8);
+        mel[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, mel[t], 0, 0, 0);
+        mel[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p2, mel[t], 0, 0, 0);
+        mel[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, p1, mel[t], 0, 0, 0);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void fbank_logmel16_kernel(const Fbank2Args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float* xs = smem + wid * V2_XS_W;
+  char* stage = reinterpret_cast<char*>(smem + WAVES * V2_XS_W);
+  float* macc = smem + wid * FT * MELP;               // after the DFT: [frame][mel] staging in the (dead) sample image
+
+  // ---- which frames does this wave own (all wave-uniform)
+  const long BT = (long)p.B * p.T;
+  const long tile = (long)blockIdx.x * WAVES + wid;
+  int bA, tA, nfA, nfB;
+  long rowA;
+  if (p.flat) {
+    const long g0 = tile * FT;
+    const long remaining = BT - g0;
+    bA = (int)(g0 / p.T);
+    tA = (int)(g0 - (long)bA * p.T);
+    int a = p.T - tA; if (a > FT) a = FT;
+    if (remaining <= 0) a = 0; else if (a > remaining) a = (int)remaining;
+    nfA = a;
+    long bmax = remaining - a; if (bmax < 0) bmax = 0;
+    nfB = FT - a; if (nfB > bmax) nfB = (int)bmax;
+    if (remaining <= 0) nfB = 0;
+    rowA = g0;
+  } else {
+    const int tps = (p.T + FT - 1) / FT;
+    bA = (int)(tile / tps);
+    tA = (int)(tile - (long)bA * tps) * FT;
+    nfA = p.T - tA; if (nfA > FT) nfA = FT;
+    if (bA >= p.B) nfA = 0;
+    nfB = 0;
+    rowA = (long)bA * p.T + tA;
+  }
+  const int nvalid = nfA + nfB;
+
+  // ---- stage the sample spans: sample `rel` of a span at word off + rel + 4 (rel / 160)
+  const int lenA = nfA > 0 ? (nfA - 1) * HOP + NFFT : 0;
+  // second span: continue the frame pattern (frame nfA at 164 nfA mod 64 words) past the end of the first span
+  int offB = lenA + 4 * (lenA / HOP) + 16;
+  offB = ((offB + 63) & ~63) + ((164 * nfA) & 63);
+  {
+    // 32 independent loads in flight per lane (a span is ~84 per lane): the wave is alone on its SIMD and the samples come
+    // from HBM, so every batch costs a full memory round trip
+    constexpr int SB = 32;
+    auto stage_span = [&](const float* src, int s0, int len, int off) {
+      for (int rel0 = lane; rel0 < len; rel0 += 64 * SB) {
+        float v[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int rel = rel0 + 64 * u;
+          int sidx = s0 + rel;
+          bool ok = rel < len;
+          if (p.pad_mode == SD_PAD_REFLECT) {
+            sidx = sidx < 0 ? -sidx : sidx;
+            sidx = sidx >= p.n ? 2 * (p.n - 1) - sidx : sidx;
+          } else {
+            ok = ok && sidx >= 0 && sidx < p.n;
+          }
+          v[u] = ok ? src[ok ? sidx : 0] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int rel = rel0 + 64 * u;
+          if (rel < len) xs[off + rel + 4 * (rel / HOP)] = v[u] * 1024.f;
+        }
+      }
+    };
+    stage_span(p.wav + (size_t)bA * p.n, tA * HOP - NFFT / 2, lenA, 0);
+    if (nfB > 0) stage_span(p.wav + (size_t)(bA + 1) * p.n, -NFFT / 2, (nfB - 1) * HOP + NFFT, offB);
+  }
+  const int j = lane & 31, h = lane >> 5;
+  int base;                                           // word of this lane's frame start
+  if (j < nfA) base = 164 * j;
+  else if (j < nvalid) base = offB + 164 * (j - nfA);
+  else base = 0;                                      // idle lane: reads something finite-or-not, never stored
+  // (every word a STORED frame reads lies inside its own 400 staged samples, except x[400], which is forced to 0)
+  __syncthreads();
+
+  f32x16 mel[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mel[t][r] = 0.f;
+  fbank2_pass<4, 0>(p, xs, base, stage, lane, wid, mel);
+  fbank2_pass<3, 4>(p, xs, base, stage, lane, wid, mel);
+  __syncthreads();                                    // every wave is done with its sample image
+
+  // mel tile rows -> LDS [frame][mel] for the log / max / coalesced-store passes below
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < p.n_mels) macc[j * MELP + m] = mel[t][r];
+    }
+  __syncthreads();
+  {
+    const int mh = (p.n_mels + 1) / 2;
+    const int m_lo = h * mh;
+    const int m_hi = (m_lo + mh < p.n_mels) ? m_lo + mh : p.n_mels;
+    float vmax = -INFINITY;
+    float* mrow = macc + j * MELP;
+    for (int m = m_lo; m < m_hi; ++m) {
+      const float v = mrow[m];
+      const float lv = (p.log_mode == SD_LOG_LN_EPS) ? logf(v + p.log_eps)
+                                                      : 10.0f * log10f(fmaxf(v, p.log_eps));
+      mrow[m] = lv;
+      vmax = fmaxf(vmax, lv);
+    }
+    const float mA = sd_wave_max(j < nfA ? vmax : -INFINITY);
+    const float mB = sd_wave_max((j >= nfA && j < nvalid) ? vmax : -INFINITY);
+    if (lane == 0) {
+      if (nfA > 0) atomicMax(p.maxbuf + bA, f32_key(mA));
+      if (nfB > 0) atomicMax(p.maxbuf + bA + 1, f32_key(mB));
+    }
+  }
+  __syncthreads();
+  {
+    const int total = nvalid * p.n_mels;
+    for (int e = lane; e < total; e += 64) {
+      const int jj = e / p.n_mels;
+      const int m = e - jj * p.n_mels;
+      p.out[(size_t)(rowA + jj) * p.ld_out + m] = macc[jj * MELP + m];
+    }
+  }
+}
+
 __global__ void fill_i32_kernel(int* p, int n, int v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -355,9 +615,27 @@ __global__ void fbank_finalize_kernel(float* out, int ld_out, int T, int n_mels,
 struct sd_fbank_plan {
   int n_fft, hop, n_mels, pad_mode, log_mode;
   float log_eps, top_db;
-  float* basis_dev;
+  float* basis_dev;        // exact-f32 kernel (SD_FBANK_V=1)
   float* mel_dev;
+  void* basis16_dev;       // split-f16 kernel: f16 [pass][k step][tile][Chi | Clo | Shi | Slo][64][8]
+  void* melw16_dev;        // bf16 [bin tile][k half][mel tile][W1 | W2][64][8]
 };
+
+namespace {
+// round-to-nearest-even f32 -> bf16 bits (finite inputs)
+unsigned short bf16_bits(float v) {
+  unsigned u;
+  std::memcpy(&u, &v, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+float bf16_value(unsigned short b) {
+  const unsigned u = (unsigned)b << 16;
+  float v;
+  std::memcpy(&v, &u, 4);
+  return v;
+}
+}  // namespace
 
 #ifdef SD_STAMP
 extern "C" int sd_debug_read_fbank_stamps(unsigned long long* out, int n) {
@@ -408,18 +686,68 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
         float* row = tab.data() + ((size_t)(q * 16 + sidx) * 2 + hh) * MELW_COLS;
         for (int m = 0; m < n_mels; ++m) row[m] = mel_fb[(size_t)bin * n_mels + m];
       }
-  sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr};
+  // ---- tables of the split-f16 kernel.  Basis: value = w[k] cos / sin(2 pi k bin / 400) in float64, hi = f16(v),
+  // lo = f16(v - hi); fragment order of v_mfma_f32_32x32x16_f16's A operand: lane l holds row (bin) l & 31,
+  // k = 16 s + 8 (l >> 5) + e.  One (pass, k step) block is contiguous: [tile in pass][kind][lane][e].
+  std::vector<_Float16> b16(V2_BASIS_BYTES / 2);
+  {
+    size_t o = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int q0 = pass == 0 ? 0 : 4, nt = pass == 0 ? 4 : 3;
+      for (int st = 0; st < V2_KSTEPS; ++st)
+        for (int qi = 0; qi < nt; ++qi)
+          for (int kind = 0; kind < 4; ++kind)
+            for (int l = 0; l < 64; ++l)
+              for (int e = 0; e < 8; ++e, ++o) {
+                const int bin = (q0 + qi) * 32 + (l & 31), k = 16 * st + 8 * (l >> 5) + e;
+                double v = 0.0;
+                if (bin < NFREQ && k <= NFFT / 2) {
+                  const int ph = (int)(((long)k * bin) % NFFT);
+                  const double ang = 2.0 * M_PI * (double)ph / (double)NFFT;
+                  v = (double)window[k] * (kind < 2 ? std::cos(ang) : std::sin(ang));
+                  if (k == NFFT / 2) v = kind < 2 ? 0.5 * v : 0.0;
+                  if (k == 0 && kind >= 2) v = 0.0;
+                }
+                const _Float16 hi = (_Float16)(float)v;
+                b16[o] = (kind & 1) ? (_Float16)(float)(v - (double)(float)hi) : hi;
+              }
+    }
+  }
+  // Mel weights as the A operand of v_mfma_f32_32x32x16_bf16 against the DFT accumulators: lane l holds row (mel)
+  // 32 t + (l & 31), element e <-> accumulator register 8 s2 + e of lane half l >> 5 = bin 32 q + 16 s2 + 8 (e >> 2) + 4 (l >> 5) + (e & 3)
+  std::vector<unsigned short> m16(V2_MELW_BYTES / 2);
+  {
+    size_t o = 0;
+    for (int q = 0; q < NBT; ++q)
+      for (int s2 = 0; s2 < 2; ++s2)
+        for (int t = 0; t < 3; ++t)
+          for (int part = 0; part < 2; ++part)
+            for (int l = 0; l < 64; ++l)
+              for (int e = 0; e < 8; ++e, ++o) {
+                const int m = 32 * t + (l & 31), bin = 32 * q + 16 * s2 + 8 * (e >> 2) + 4 * (l >> 5) + (e & 3);
+                const float w = (m < n_mels && bin < NFREQ) ? mel_fb[(size_t)bin * n_mels + m] : 0.f;
+                const unsigned short w1 = bf16_bits(w);
+                m16[o] = part == 0 ? w1 : bf16_bits(w - bf16_value(w1));
+              }
+  }
+  sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr, nullptr, nullptr};
   hipError_t e1 = hipMalloc(&plan->basis_dev, basis.size() * sizeof(float));
   hipError_t e2 = e1 == hipSuccess ? hipMalloc(&plan->mel_dev, tab.size() * sizeof(float)) : e1;
+  if (e2 == hipSuccess) e1 = hipMalloc(&plan->basis16_dev, V2_BASIS_BYTES);
+  if (e1 == hipSuccess && e2 == hipSuccess) e2 = hipMalloc(&plan->melw16_dev, V2_MELW_BYTES);
   if (e1 == hipSuccess && e2 == hipSuccess) {
     e1 = hipMemcpy(plan->basis_dev, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice);
     e2 = hipMemcpy(plan->mel_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e1 == hipSuccess) e1 = hipMemcpy(plan->basis16_dev, b16.data(), V2_BASIS_BYTES, hipMemcpyHostToDevice);
+    if (e2 == hipSuccess) e2 = hipMemcpy(plan->melw16_dev, m16.data(), V2_MELW_BYTES, hipMemcpyHostToDevice);
   }
   if (e1 != hipSuccess || e2 != hipSuccess) {
     sd_set_error(SD_ERR_HIP, "sd_fbank_plan_create: device table upload failed: %s",
                  hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     if (plan->basis_dev) (void)hipFree(plan->basis_dev);
     if (plan->mel_dev) (void)hipFree(plan->mel_dev);
+    if (plan->basis16_dev) (void)hipFree(plan->basis16_dev);
+    if (plan->melw16_dev) (void)hipFree(plan->melw16_dev);
     delete plan;
     return nullptr;
   }
@@ -430,6 +758,8 @@ extern "C" void sd_fbank_plan_destroy(sd_fbank_plan* plan) {
   if (!plan) return;
   (void)hipFree(plan->basis_dev);
   (void)hipFree(plan->mel_dev);
+  (void)hipFree(plan->basis16_dev);
+  (void)hipFree(plan->melw16_dev);
   delete plan;
 }
 
@@ -473,12 +803,25 @@ extern "C" int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int
   // replayed from a captured hipGraph did not reproduce the eager result (configs[3] test)
   hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a.maxbuf, B, (int)0x80808080);
   SD_CHECK_LAUNCH("fill_i32_kernel");
-  const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
-  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(fbank_logmel_kernel), (int)lds));
-  {
+  static const int version = [] {          // SD_FBANK_V=1: the exact-f32 MFMA kernel of round 1 (A/B runs)
+    const char* e = getenv("SD_FBANK_V");
+    return e && e[0] == '1' ? 1 : 2;
+  }();
+  if (version == 1) {
+    const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
+    SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(fbank_logmel_kernel), (int)lds));
     // algorithmic bytes: waveform read once + log-mel written once (192 320 B per 2 s segment)
     SdProfScope prof(SD_PROF_FBANK, stream, (double)B * ((double)n * 4.0 + (double)T * plan->n_mels * 4.0));
     hipLaunchKernelGGL(fbank_logmel_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  } else {
+    Fbank2Args a2;
+    a2.wav = wav_dev; a2.B = B; a2.n = n; a2.T = T;
+    a2.basis = static_cast<const _Float16*>(plan->basis16_dev); a2.melw = static_cast<const __bf16*>(plan->melw16_dev);
+    a2.n_mels = plan->n_mels; a2.pad_mode = plan->pad_mode; a2.log_mode = plan->log_mode; a2.log_eps = plan->log_eps;
+    a2.out = out_dev; a2.ld_out = ld_out; a2.maxbuf = a.maxbuf; a2.flat = a.flat;
+    SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(fbank_logmel16_kernel), V2_LDS_BYTES));
+    SdProfScope prof(SD_PROF_FBANK, stream, (double)B * ((double)n * 4.0 + (double)T * plan->n_mels * 4.0));
+    hipLaunchKernelGGL(fbank_logmel16_kernel, dim3((unsigned)blocks), dim3(256), V2_LDS_BYTES, stream, a2);
   }
   SD_CHECK_LAUNCH("fbank_logmel_kernel");
   const int use_floor = plan->log_mode == SD_LOG_DB_TOPDB && plan->top_db >= 0.f;

@@ -33,6 +33,28 @@ def test_fbank_matches_oracle(dev, kind, B, n):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("kind", ["torchaudio", "speechbrain"])
+@pytest.mark.parametrize("level", [1.0, 1e-2, 3e-5, 1e-6])
+def test_fbank_keeps_its_accuracy_at_every_signal_level(dev, kind, level):
+    """The DFT runs on the f16 matrix cores with every operand split hi + lo; the samples are scaled by 2^10 first so that
+    the low halves stay out of the f16 subnormals.  Full scale (|x| up to 1: folded sums up to 2048, no f16 overflow), a
+    quiet stretch, one 16-bit LSB (3e-5) and far below: the error against float64 does not depend on the level."""
+    from oracle import fbank_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import fbank_device
+    from speech_diarization_amd.features import FbankPlan
+    wav = synth.synthetic_segments(17, 3, 16000, std=0.3).astype(np.float64)
+    wav = np.clip(wav / np.abs(wav).max(), -1, 1) * level            # peak exactly `level`
+    wav[1, 5000:5400] = level                                          # a clipped plateau: x[k] + x[400 - k] = 2 * level
+    wav = wav.astype(np.float32)
+    plan = FbankPlan(kind)
+    got = fbank_device(torch.from_numpy(wav).to(dev), plan, mean_norm=False).cpu().numpy()
+    ref = fbank_ref.fbank_batch_ref(wav, mean_nor=False) if kind == "torchaudio" else fbank_ref.speechbrain_fbank_ref(wav, mean_norm=False)
+    assert np.isfinite(got).all()
+    tol = 2e-4 if kind == "torchaudio" else 1e-3
+    assert np.abs(got - ref).max() < tol, (level, np.abs(got - ref).max())
+
+
 def test_fbank_known_answers(dev):
     """all-zero waveform -> every bin log(eps) -> exactly 0 after mean-norm; pure tone -> peak at its mel bin."""
     from speech_diarization_amd.engine import fbank_device
