@@ -10,323 +10,19 @@
 // DFT folds to K = 201:
 //     Re X[n] = sum_{k=0..200} Cb[k][n] * (x[k] + x[400-k]),   Cb = w[k] cos(2 pi k n / 400)
 //     Im X[n] = sum_{k=1..199} Sb[k][n] * (x[k] - x[400-k]),   Sb = w[k] sin(2 pi k n / 400)
-// (x[400] := 0 for k = 0, Cb[200] halved), i.e. two GEMMs  [bins x K] * [K x frames]
-// that run on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 fma chain).
-// The basis is a host-computed table; a wave owns 32 consecutive frames, keeps their
-// sample span in LDS (each sample is fetched from HBM once per tile, 4.5 % overlap) and
-// forms the folded operands on the fly.  The mel energies are a third product on the same
-// matrix cores, mel[m][frame] += W[bin][m] * |X[bin][frame]|^2, fed straight from the DFT
-// accumulators (no scatter through LDS).  Tiles are flat over (utterance, frame) so no lane
-// idles on T = 201.
+// (x[400] := 0 for k = 0, Cb[200] halved), i.e. two GEMMs  [bins x K] * [K x frames] with a host-computed basis.
+// A wave owns 32 consecutive frames and keeps their sample span in LDS (each sample is fetched from HBM once per
+// tile, 4.5 % overlap); tiles are flat over (utterance, frame) so no lane idles on T = 201.
 //
-// LDS: sample spans are skewed by one word per 160 samples so that the 32 frames of
-// a tile (stride 160 words = 0 mod 32 banks) hit 32 distinct banks; the six K chunks of a
-// frequency tile are unrolled so every operand read is a ds_read with an immediate offset.
-//
-// Round-1 measurements that shaped it (tools/stamp_fbank.py, in-kernel cycle counters): a per-lane
-// read-modify-write scatter of |X|^2 into LDS mel accumulators took 41 % of the kernel (LDS
-// float adds no better) -> MFMA mel; one-chunk-ahead basis prefetch stalled on L2 -> two register
-// stages; per-lane address arithmetic for the skewed reads cost as much issue time as the
-// MFMAs -> immediate offsets.  4.9 -> 3.0 ms per 5000 segments.
-#include "sd_common.h"
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <vector>
-
-namespace {
-
-constexpr int NFFT = 400;
-constexpr int HOP = 160;
-constexpr int NFREQ = 201;
-constexpr int KP = 204;      // folded K, padded
-constexpr int KC = 34;       // K per staged basis chunk
-constexpr int NCHUNK = KP / KC;  // 6
-constexpr int NBT = 7;       // 32-bin tiles (224 >= 201)
-constexpr int FT = 32;       // frames per wave tile
-constexpr int WAVES = 4;
-constexpr int XS_W = 5760;   // per-wave sample LDS, floats
-constexpr int MELP = 81;     // mel accumulator row stride
-constexpr int MAX_MELS = 80;
-constexpr int CHUNK_FLOATS = KC * 64;  // [KC][cos 32 | sin 32]
-constexpr int MELW_COLS = 96;                 // mel filters padded to three 32-wide MFMA tiles
-constexpr int MELW_FLOATS = NBT * 16 * 2 * MELW_COLS;
-constexpr int LDS_FLOATS = WAVES * XS_W + WAVES * FT * MELP + 2 * CHUNK_FLOATS;
-
-
-struct FbankArgs {
-  const float* wav; int B; int n; int T;
-  const float* basis;      // [NBT][KP][64]
-  const float* melw;       // [NBT][16][2][MELW_COLS]: mel weights in the order the MFMA accumulators hold the bins
-  int n_mels; int pad_mode; int log_mode; float log_eps;
-  float* out; int ld_out;
-  int* maxbuf;             // [B] ordered-int keys of the utterance max
-  int flat;                // tiles flat over B*T (T >= 32) or one tile row per utterance
-};
-
-__device__ __forceinline__ int f32_key(float v) {
-  const int b = __float_as_int(v);
-  return b >= 0 ? b : b ^ 0x7FFFFFFF;
-}
-__device__ __forceinline__ float key_f32(int k) {
-  return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF);
-}
-
-#ifdef SD_STAMP
-__device__ unsigned long long sd_fb_stamp_buf[8192 * 8];
-#define FB_TSEG(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tacc[i] += now_ - tprev; tprev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define FB_TSEG(i) do { } while (0)
-#endif
-
-__global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const FbankArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-#ifdef SD_STAMP
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tprev = __builtin_amdgcn_s_memtime();
-#endif
-  float* xs = smem + wid * XS_W;
-  float* macc = smem + WAVES * XS_W + wid * FT * MELP;
-  float* bs = smem + WAVES * XS_W + WAVES * FT * MELP;
-
-  // ---- which frames does this wave own (all wave-uniform)
-  const long BT = (long)p.B * p.T;
-  const long tile = (long)blockIdx.x * WAVES + wid;
-  int bA, tA, nfA, nfB;
-  long rowA;
-  if (p.flat) {
-    const long g0 = tile * FT;
-    const long remaining = BT - g0;
-    bA = (int)(g0 / p.T);
-    tA = (int)(g0 - (long)bA * p.T);
-    int a = p.T - tA; if (a > FT) a = FT;
-    if (remaining <= 0) a = 0; else if (a > remaining) a = (int)remaining;
-    nfA = a;
-    long bmax = remaining - a; if (bmax < 0) bmax = 0;
-    nfB = FT - a; if (nfB > bmax) nfB = (int)bmax;
-    if (remaining <= 0) nfB = 0;
-    rowA = g0;
-  } else {
-    const int tps = (p.T + FT - 1) / FT;
-    bA = (int)(tile / tps);
-    tA = (int)(tile - (long)bA * tps) * FT;
-    nfA = p.T - tA; if (nfA > FT) nfA = FT;
-    if (bA >= p.B) nfA = 0;
-    nfB = 0;
-    rowA = (long)bA * p.T + tA;
-  }
-  const int nvalid = nfA + nfB;
-
-  // ---- stage sample spans (skewed) into this wave's LDS
-  const int lenA = nfA > 0 ? (nfA - 1) * HOP + NFFT : 0;
-  int offB = lenA + lenA / HOP + 1;
-  offB = ((offB + 31) & ~31) + (nfA & 31);
-  {
-    // 8 independent loads in flight per lane, then 8 LDS writes (a one-load-per-iteration loop pays a
-    // full memory round trip 88 times per tile)
-    auto stage_span = [&](const float* src, int s0, int len, int off) {
-      for (int rel0 = lane; rel0 < len; rel0 += 64 * 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rel = rel0 + 64 * u;
-          int sidx = s0 + rel;
-          bool ok = rel < len;
-          if (p.pad_mode == SD_PAD_REFLECT) {
-            sidx = sidx < 0 ? -sidx : sidx;
-            sidx = sidx >= p.n ? 2 * (p.n - 1) - sidx : sidx;
-          } else {
-            ok = ok && sidx >= 0 && sidx < p.n;
-          }
-          v[u] = ok ? src[ok ? sidx : 0] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rel = rel0 + 64 * u;
-          if (rel < len) xs[off + rel + rel / HOP] = v[u];
-        }
-      }
-    };
-    stage_span(p.wav + (size_t)bA * p.n, tA * HOP - NFFT / 2, lenA, 0);
-    if (nfB > 0) stage_span(p.wav + (size_t)(bA + 1) * p.n, -NFFT / 2, (nfB - 1) * HOP + NFFT, offB);
-  }
-  FB_TSEG(0);   // tile bookkeeping + sample staging
-
-  const int j = lane & 31;   // frame within tile (MFMA column)
-  const int h = lane >> 5;   // k slot / row half
-  int base;                  // skewed LDS word of this lane's frame start
-  if (j < nfA) base = 161 * j;
-  else if (j < nvalid) base = offB + 161 * (j - nfA);
-  else base = 0;             // idle lane: reads something harmless, never stored
-
-  // ---- basis chunk pipeline (all 4 waves share the staged chunk)
-  // two register stages: the chunk after next is already in flight while this one is multiplied
-  // (a chunk is only 34 MFMAs = 2176 cycles, less than an L2 round trip under load)
-  struct Pre { f32x4 v[3]; };
-  Pre preA, preB;
-  auto bload = [&](Pre& r, int ch) {
-    const f32x4* g = reinterpret_cast<const f32x4*>(p.basis + (size_t)ch * CHUNK_FLOATS);
-    r.v[0] = g[tid];
-    r.v[1] = g[tid + 256];
-    if (tid < CHUNK_FLOATS / 4 - 512) r.v[2] = g[tid + 512];
-  };
-  auto bstore = [&](const Pre& r, int buf) {
-    f32x4* d = reinterpret_cast<f32x4*>(bs + buf * CHUNK_FLOATS);
-    d[tid] = r.v[0];
-    d[tid + 256] = r.v[1];
-    if (tid < CHUNK_FLOATS / 4 - 512) d[tid + 512] = r.v[2];
-  };
-  constexpr int NCH_TOTAL = NBT * NCHUNK;
-  static_assert(NCHUNK % 2 == 0, "the chunk loop is unrolled by two register stages");
-
-  bload(preA, 0);
-  bstore(preA, 0);
-  bload(preB, 1);      // chunk 1 -> stored at the end of chunk 0
-  bload(preA, 2);      // chunk 2 -> stored at the end of chunk 1
-  __syncthreads();
-
-  // mel energies accumulate on the matrix cores too: mel[m][frame] += W[bin][m] * |X[bin][frame]|^2 with the
-  // power spectrum taken straight from the DFT accumulators as the B operand (lane half h supplies bin
-  // 32q + (s&3) + 8(s>>2) + 4h at step s) — no per-lane scatter through LDS
-  f32x16 mel[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mel[t][r] = 0.f;
-
-  for (int q = 0; q < NBT; ++q) {
-    f32x16 accRe, accIm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { accRe[r] = 0.f; accIm[r] = 0.f; }
-    // this tile's mel weights: 48 coalesced dword loads issued now, consumed after the DFT of the tile
-    float mw[16][3];
-    {
-      const float* wq = p.melw + ((size_t)(q * 16) * 2 + h) * MELW_COLS + j;
-#pragma unroll
-      for (int sidx = 0; sidx < 16; ++sidx)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) mw[sidx][t] = wq[(size_t)sidx * 2 * MELW_COLS + 32 * t];
-    }
-
-    // The six chunks of a tile are unrolled, so every k below is a compile-time constant and each operand
-    // read is a ds_read with an immediate offset from one of three per-lane bases (no address VALU in the
-    // loop): lane half h handles k = k0 + h; x[k] sits at pa[skew(k0)], x[400 - k] at pb1/pb2[skew(400 - k0)]
-    // (the skewed offset steps by 2 instead of 1 where 400 - k0 is exactly 160 or 320).
-    const float* pa = xs + base + h;
-    const float* pb1 = xs + base - h;
-    const float* pb2 = xs + base - 2 * h;
-    auto chunk = [&](const int c, Pre& st) {
-      // `st` holds chunk ch+1 (written to the other LDS stage at the end), then refills with chunk ch+3
-      const int ch = q * NCHUNK + c;
-      const int buf = c & 1;                                  // NCHUNK is even: the stage parity restarts with each tile
-      const float* bcur = bs + buf * CHUNK_FLOATS + h * 64 + j;
-      // software pipeline inside the chunk: the LDS operands of step kk + PD are requested right before
-      // the two MFMAs of step kk (the wave is alone on its SIMD; left to itself the scheduler puts an LDS
-      // round trip in front of every MFMA pair).  sched_barrier pins that order.
-      constexpr int PD = 4;
-      float xa[KC / 2], xb[KC / 2], cb[KC / 2], sb[KC / 2];
-      auto fetch = [&](const int kk) {
-        const int k0 = c * KC + 2 * kk;
-        const int kb0 = NFFT - k0;
-        const int ka_s = k0 + (k0 >= HOP) + (k0 >= 2 * HOP);
-        const int kb_s = kb0 + (kb0 >= HOP) + (kb0 >= 2 * HOP);
-        xa[kk] = pa[ka_s];
-        const float t = (kb0 == HOP || kb0 == 2 * HOP) ? pb2[kb_s] : pb1[kb_s];
-        xb[kk] = (k0 == 0 && h == 0) ? 0.f : t;
-        cb[kk] = bcur[kk * 128];
-        sb[kk] = bcur[kk * 128 + 32];
-      };
-#pragma unroll
-      for (int kk = 0; kk < PD; ++kk) fetch(kk);
-#pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) {
-        if (kk + PD < KC / 2) fetch(kk + PD);
-        accRe = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[kk], xa[kk] + xb[kk], accRe, 0, 0, 0);
-        accIm = __builtin_amdgcn_mfma_f32_32x32x2f32(sb[kk], xa[kk] - xb[kk], accIm, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      FB_TSEG(1);   // operand reads + MFMA
-      if (ch + 1 < NCH_TOTAL) bstore(st, buf ^ 1);
-      if (ch + 3 < NCH_TOTAL) bload(st, ch + 3);
-      __syncthreads();
-      FB_TSEG(2);   // basis stage write + barrier
-    };
-#pragma unroll
-    for (int c = 0; c < NCHUNK; c += 2) {
-      chunk(c, preB);
-      chunk(c + 1, preA);
-    }
-
-    // ---- |X|^2 -> mel: 16 x 3 MFMAs per frequency tile
-#pragma unroll
-    for (int sidx = 0; sidx < 16; ++sidx) {
-      const float pw = accRe[sidx] * accRe[sidx] + accIm[sidx] * accIm[sidx];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) mel[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mw[sidx][t], pw, mel[t], 0, 0, 0);
-    }
-    FB_TSEG(3);     // |X|^2 -> mel
-  }
-  // mel tile rows -> LDS [frame][mel] for the log / max / coalesced-store passes below
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m < p.n_mels) macc[j * MELP + m] = mel[t][r];
-    }
-  __syncthreads();
-
-  // ---- log + utterance max; lane (j, h) takes half of the mel bins of frame j
-  {
-    const int mh = (p.n_mels + 1) / 2;
-    const int m_lo = h * mh;
-    const int m_hi = (m_lo + mh < p.n_mels) ? m_lo + mh : p.n_mels;
-    float vmax = -INFINITY;
-    float* mrow = macc + j * MELP;
-    for (int m = m_lo; m < m_hi; ++m) {
-      const float v = mrow[m];
-      const float lv = (p.log_mode == SD_LOG_LN_EPS) ? logf(v + p.log_eps)
-                                                      : 10.0f * log10f(fmaxf(v, p.log_eps));
-      mrow[m] = lv;
-      vmax = fmaxf(vmax, lv);
-    }
-    const float mA = sd_wave_max(j < nfA ? vmax : -INFINITY);
-    const float mB = sd_wave_max((j >= nfA && j < nvalid) ? vmax : -INFINITY);
-    if (lane == 0) {
-      if (nfA > 0) atomicMax(p.maxbuf + bA, f32_key(mA));
-      if (nfB > 0) atomicMax(p.maxbuf + bA + 1, f32_key(mB));
-    }
-  }
-  __syncthreads();
-  FB_TSEG(4);       // log, utterance max
-  // ---- coalesced store of the tile's [nvalid][n_mels] block
-  {
-    const int total = nvalid * p.n_mels;
-    for (int e = lane; e < total; e += 64) {
-      const int jj = e / p.n_mels;
-      const int m = e - jj * p.n_mels;
-      p.out[(size_t)(rowA + jj) * p.ld_out + m] = macc[jj * MELP + m];
-    }
-  }
-#ifdef SD_STAMP
-  FB_TSEG(5);
-  if (tid == 0 && blockIdx.x < 8192)
-    for (int i = 0; i < 8; ++i) sd_fb_stamp_buf[blockIdx.x * 8 + i] = tacc[i];
-#endif
-}
-
-// ==========================================================================================
-// Version 2 of the main kernel: the same folded DFT, on the f16 matrix cores at f32 accuracy.
-//
-// The exact-f32 MFMA runs at 1/16 of the f16 rate, and round 1's kernel was bound by it (ideal MFMA time 1.4 ms of its
-// 3.0 ms per 5000 segments).  Here every f32 operand is split into two halves, v = hi + lo with hi = f16(v) and
-// lo = f16(v - hi), and a product is  hi.hi + hi.lo + lo.hi  on v_mfma_f32_32x32x16_f16 with f32 accumulation: the
-// dropped lo.lo term and the representation error are 2^-22 relative per product, i.e. f32-level, for three MFMAs
-// that do sixteen times the work of an f32 one (the scheme of the split-precision affinity, sd_pool.hip).  The samples
-// are scaled by 2^10 when staged (folded sums <= 2048 < f16 max) so that the LOW halves stay clear of the f16
-// subnormals down to signals of 1e-7 full scale (what matters for a quiet segment is the error relative to ITS level:
-// unscaled, a -100 dBFS segment would keep only ~12 bits); the power spectrum takes 2^-20 back, exactly.
+// The products run on the F16 matrix cores at f32 accuracy.  The exact-f32 MFMA runs at 1/16 of the f16 rate, and
+// round 1's kernel (v_mfma_f32_32x32x2_f32) was bound by it: ideal MFMA time 1.4 ms of its 3.0 ms per 5000 segments.
+// Here every f32 operand is split into two halves, v = hi + lo with hi = f16(v) and lo = f16(v - hi), and a product
+// is  hi.hi + hi.lo + lo.hi  on v_mfma_f32_32x32x16_f16 with f32 accumulation: the dropped lo.lo term and the
+// representation error are 2^-22 relative per product, i.e. f32-level, for three MFMAs that do sixteen times the
+// work of an f32 one (the scheme of the split-precision affinity, sd_pool.hip).  The samples are scaled by 2^10
+// (folded sums <= 2048 < f16 max) so that the LOW halves stay clear of the f16 subnormals down to signals of 1e-7
+// full scale (what matters for a quiet segment is the error relative to ITS level: unscaled, a -100 dBFS segment
+// would keep only ~12 bits); the power spectrum takes 2^-20 back, exactly.
 //   * DFT: 6 MFMAs per (32-bin tile, 16 k): 546 of 32 cycles per wave tile instead of 1428 of 64.
 //   * mel: |X|^2 goes from the DFT accumulators straight into the next MFMA as its B operand (the accumulator rows are
 //     the next product's k: no lane movement), split into two bf16 halves (f32 exponent range), against mel weights
@@ -338,6 +34,40 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const FbankArgs p)
 //   * LDS sample image: sample i of a span sits at word i + 4 (i / 160): frame starts (stride 164 words) and every
 //     aligned group of 4 samples stay 16-byte aligned, and the 16 frames of a ds_read_b128 lane group fall on 16
 //     distinct bank slots (41 j mod 16 = 9 j).
+// Measured (MI355X, 5000 segments of 2 s): 1.40 ms main kernel + 0.21 ms finalize (round 1: 3.0 + 0.21), 687 GB/s of the
+// 192 320 algorithmic bytes per segment.  Two things found on the way (both hipcc codegen, both worth ~1 ms):
+// a multiply placed next to the staging loads made every load wait on its own (79 `s_waitcnt vmcnt(0)`), and predicated
+// loads become branches with a wait each; the staging loop therefore loads unconditionally from a clamped index and
+// selects the zero padding afterwards.
+#include "sd_common.h"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int NFFT = 400;
+constexpr int HOP = 160;
+constexpr int NFREQ = 201;
+constexpr int NBT = 7;       // 32-bin tiles (224 >= 201)
+constexpr int FT = 32;       // frames per wave tile
+constexpr int WAVES = 4;
+constexpr int MELP = 81;     // mel accumulator row stride
+constexpr int MAX_MELS = 80;
+
+
+__device__ __forceinline__ int f32_key(float v) {
+  const int b = __float_as_int(v);
+  return b >= 0 ? b : b ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float key_f32(int k) {
+  return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF);
+}
+
+#ifndef SD_FB_SCALE
+#define SD_FB_SCALE 1024.f
+#endif
 constexpr int V2_XS_W = 5952;                       // per-wave sample image, floats (two spans + skew + alignment slack)
 constexpr int V2_STAGE_BYTES = 16 * 1024;           // basis fragments of one (pass, k step): 4 tiles x 4 kinds x 1 KB
 constexpr int V2_KSTEPS = 13;                       // 208 / 16
@@ -403,7 +133,9 @@ __device__ __forceinline__ void fbank2_pass(const Fbank2Args& p, const float* xs
     h8v ahi, alo, dhi, dlo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float a = fwd[e] + bwd[e], d = fwd[e] - bwd[e];                 // (samples were scaled by 2^10 when staged)
+      // scaled HERE, not when the samples are staged: a multiply next to the staging loads makes hipcc wait for every
+      // load separately (79 `s_waitcnt vmcnt(0)`, 1.0 ms more per 5000 segments)
+      const float a = SD_FB_SCALE * (fwd[e] + bwd[e]), d = SD_FB_SCALE * (fwd[e] - bwd[e]);
       ahi[e] = (_Float16)a; alo[e] = (_Float16)(a - (float)ahi[e]);
       dhi[e] = (_Float16)d; dlo[e] = (_Float16)(d - (float)dhi[e]);
     }
@@ -433,7 +165,7 @@ __device__ __forceinline__ void fbank2_pass(const Fbank2Args& p, const float* xs
       bf8v p1, p2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float pw = (re[q][8 * s2 + e] * re[q][8 * s2 + e] + im[q][8 * s2 + e] * im[q][8 * s2 + e]) * 0x1p-20f;
+        const float pw = (re[q][8 * s2 + e] * re[q][8 * s2 + e] + im[q][8 * s2 + e] * im[q][8 * s2 + e]) * (1.0f / (SD_FB_SCALE * SD_FB_SCALE));
         p1[e] = (__bf16)pw;
         p2[e] = (__bf16)(pw - (float)p1[e]);
       }
@@ -449,7 +181,7 @@ __device__ __forceinline__ void fbank2_pass(const Fbank2Args& p, const float* xs
   }
 }
 
-__global__ __launch_bounds__(256, 1) void fbank_logmel16_kernel(const Fbank2Args p) {
+__global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const Fbank2Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float* xs = smem + wid * V2_XS_W;
@@ -496,23 +228,28 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel16_kernel(const Fbank2Args
     auto stage_span = [&](const float* src, int s0, int len, int off) {
       for (int rel0 = lane; rel0 < len; rel0 += 64 * SB) {
         float v[SB];
+        bool okv[SB];
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-          const int rel = rel0 + 64 * u;
+        for (int u = 0; u < SB; ++u) {                // unconditional loads from a clamped index (a predicated load becomes a
+          const int rel = rel0 + 64 * u;              // branch and a wait of its own), zero padding selected afterwards
           int sidx = s0 + rel;
-          bool ok = rel < len;
+          bool ok = true;
           if (p.pad_mode == SD_PAD_REFLECT) {
             sidx = sidx < 0 ? -sidx : sidx;
             sidx = sidx >= p.n ? 2 * (p.n - 1) - sidx : sidx;
           } else {
-            ok = ok && sidx >= 0 && sidx < p.n;
+            ok = sidx >= 0 && sidx < p.n;
           }
-          v[u] = ok ? src[ok ? sidx : 0] : 0.f;
+          sidx = sidx < 0 ? 0 : (sidx >= p.n ? p.n - 1 : sidx);
+          okv[u] = ok;
+          v[u] = src[sidx];
         }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) v[u] = okv[u] ? v[u] : 0.f;
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
           const int rel = rel0 + 64 * u;
-          if (rel < len) xs[off + rel + 4 * (rel / HOP)] = v[u] * 1024.f;
+          if (rel < len) xs[off + rel + 4 * (rel / HOP)] = v[u];
         }
       }
     };
@@ -615,8 +352,6 @@ __global__ void fbank_finalize_kernel(float* out, int ld_out, int T, int n_mels,
 struct sd_fbank_plan {
   int n_fft, hop, n_mels, pad_mode, log_mode;
   float log_eps, top_db;
-  float* basis_dev;        // exact-f32 kernel (SD_FBANK_V=1)
-  float* mel_dev;
   void* basis16_dev;       // split-f16 kernel: f16 [pass][k step][tile][Chi | Clo | Shi | Slo][64][8]
   void* melw16_dev;        // bf16 [bin tile][k half][mel tile][W1 | W2][64][8]
 };
@@ -637,14 +372,6 @@ float bf16_value(unsigned short b) {
 }
 }  // namespace
 
-#ifdef SD_STAMP
-extern "C" int sd_debug_read_fbank_stamps(unsigned long long* out, int n) {
-  SD_CHECK_HIP(hipDeviceSynchronize());
-  SD_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(sd_fb_stamp_buf), (size_t)n * sizeof(unsigned long long)));
-  return SD_OK;
-}
-#endif
-
 extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, int hop,
                                                const float* mel_fb, int n_mels,
                                                int pad_mode, int log_mode, float log_eps, float top_db) {
@@ -659,33 +386,6 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
     if (window[k] != window[NFFT - k])
       return fail(SD_ERR_UNSUPPORTED, "sd_fbank_plan_create: window must be symmetric (w[k] == w[n_fft-k])");
 
-  std::vector<float> basis((size_t)NBT * KP * 64, 0.f);
-  for (int q = 0; q < NBT; ++q)
-    for (int k = 0; k <= NFFT / 2; ++k)
-      for (int i = 0; i < 32; ++i) {
-        const int bin = q * 32 + i;
-        if (bin >= NFREQ) continue;
-        // reduce k*bin mod 400 in integers so the angle stays small and exact
-        const int ph = (int)(((long)k * bin) % NFFT);
-        const double ang = 2.0 * M_PI * (double)ph / (double)NFFT;
-        double cw = (double)window[k] * std::cos(ang);
-        double sw = (double)window[k] * std::sin(ang);
-        if (k == NFFT / 2) { cw *= 0.5; sw = 0.0; }
-        if (k == 0) sw = 0.0;
-        float* row = basis.data() + ((size_t)q * KP + k) * 64;
-        row[i] = (float)cw;
-        row[32 + i] = (float)sw;
-      }
-  // dense mel weights in accumulator order: entry [q][s][h][m] belongs to bin 32q + (s&3) + 8(s>>2) + 4h
-  std::vector<float> tab((size_t)MELW_FLOATS, 0.f);
-  for (int q = 0; q < NBT; ++q)
-    for (int sidx = 0; sidx < 16; ++sidx)
-      for (int hh = 0; hh < 2; ++hh) {
-        const int bin = 32 * q + (sidx & 3) + 8 * (sidx >> 2) + 4 * hh;
-        if (bin >= NFREQ) continue;
-        float* row = tab.data() + ((size_t)(q * 16 + sidx) * 2 + hh) * MELW_COLS;
-        for (int m = 0; m < n_mels; ++m) row[m] = mel_fb[(size_t)bin * n_mels + m];
-      }
   // ---- tables of the split-f16 kernel.  Basis: value = w[k] cos / sin(2 pi k bin / 400) in float64, hi = f16(v),
   // lo = f16(v - hi); fragment order of v_mfma_f32_32x32x16_f16's A operand: lane l holds row (bin) l & 31,
   // k = 16 s + 8 (l >> 5) + e.  One (pass, k step) block is contiguous: [tile in pass][kind][lane][e].
@@ -730,22 +430,16 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
                 m16[o] = part == 0 ? w1 : bf16_bits(w - bf16_value(w1));
               }
   }
-  sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr, nullptr, nullptr};
-  hipError_t e1 = hipMalloc(&plan->basis_dev, basis.size() * sizeof(float));
-  hipError_t e2 = e1 == hipSuccess ? hipMalloc(&plan->mel_dev, tab.size() * sizeof(float)) : e1;
-  if (e2 == hipSuccess) e1 = hipMalloc(&plan->basis16_dev, V2_BASIS_BYTES);
-  if (e1 == hipSuccess && e2 == hipSuccess) e2 = hipMalloc(&plan->melw16_dev, V2_MELW_BYTES);
+  sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr};
+  hipError_t e1 = hipMalloc(&plan->basis16_dev, V2_BASIS_BYTES);
+  hipError_t e2 = e1 == hipSuccess ? hipMalloc(&plan->melw16_dev, V2_MELW_BYTES) : e1;
   if (e1 == hipSuccess && e2 == hipSuccess) {
-    e1 = hipMemcpy(plan->basis_dev, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice);
-    e2 = hipMemcpy(plan->mel_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e1 == hipSuccess) e1 = hipMemcpy(plan->basis16_dev, b16.data(), V2_BASIS_BYTES, hipMemcpyHostToDevice);
-    if (e2 == hipSuccess) e2 = hipMemcpy(plan->melw16_dev, m16.data(), V2_MELW_BYTES, hipMemcpyHostToDevice);
+    e1 = hipMemcpy(plan->basis16_dev, b16.data(), V2_BASIS_BYTES, hipMemcpyHostToDevice);
+    e2 = hipMemcpy(plan->melw16_dev, m16.data(), V2_MELW_BYTES, hipMemcpyHostToDevice);
   }
   if (e1 != hipSuccess || e2 != hipSuccess) {
     sd_set_error(SD_ERR_HIP, "sd_fbank_plan_create: device table upload failed: %s",
                  hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-    if (plan->basis_dev) (void)hipFree(plan->basis_dev);
-    if (plan->mel_dev) (void)hipFree(plan->mel_dev);
     if (plan->basis16_dev) (void)hipFree(plan->basis16_dev);
     if (plan->melw16_dev) (void)hipFree(plan->melw16_dev);
     delete plan;
@@ -756,8 +450,6 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
 
 extern "C" void sd_fbank_plan_destroy(sd_fbank_plan* plan) {
   if (!plan) return;
-  (void)hipFree(plan->basis_dev);
-  (void)hipFree(plan->mel_dev);
   (void)hipFree(plan->basis16_dev);
   (void)hipFree(plan->melw16_dev);
   delete plan;
@@ -789,9 +481,9 @@ extern "C" int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int
   SD_CHECK_ARG(ws_dev != nullptr && ws_bytes >= sd_fbank_workspace_bytes(plan, B, n),
                "sd_fbank_f32: workspace too small (%zu < %zu)", ws_bytes, sd_fbank_workspace_bytes(plan, B, n));
   const int T = 1 + n / HOP;
-  FbankArgs a;
+  Fbank2Args a;
   a.wav = wav_dev; a.B = B; a.n = n; a.T = T;
-  a.basis = plan->basis_dev; a.melw = plan->mel_dev;
+  a.basis = static_cast<const _Float16*>(plan->basis16_dev); a.melw = static_cast<const __bf16*>(plan->melw16_dev);
   a.n_mels = plan->n_mels; a.pad_mode = plan->pad_mode; a.log_mode = plan->log_mode; a.log_eps = plan->log_eps;
   a.out = out_dev; a.ld_out = ld_out;
   a.maxbuf = static_cast<int*>(ws_dev);
@@ -803,25 +495,11 @@ extern "C" int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int
   // replayed from a captured hipGraph did not reproduce the eager result (configs[3] test)
   hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a.maxbuf, B, (int)0x80808080);
   SD_CHECK_LAUNCH("fill_i32_kernel");
-  static const int version = [] {          // SD_FBANK_V=1: the exact-f32 MFMA kernel of round 1 (A/B runs)
-    const char* e = getenv("SD_FBANK_V");
-    return e && e[0] == '1' ? 1 : 2;
-  }();
-  if (version == 1) {
-    const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
-    SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(fbank_logmel_kernel), (int)lds));
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(fbank_logmel_kernel), V2_LDS_BYTES));
+  {
     // algorithmic bytes: waveform read once + log-mel written once (192 320 B per 2 s segment)
     SdProfScope prof(SD_PROF_FBANK, stream, (double)B * ((double)n * 4.0 + (double)T * plan->n_mels * 4.0));
-    hipLaunchKernelGGL(fbank_logmel_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-  } else {
-    Fbank2Args a2;
-    a2.wav = wav_dev; a2.B = B; a2.n = n; a2.T = T;
-    a2.basis = static_cast<const _Float16*>(plan->basis16_dev); a2.melw = static_cast<const __bf16*>(plan->melw16_dev);
-    a2.n_mels = plan->n_mels; a2.pad_mode = plan->pad_mode; a2.log_mode = plan->log_mode; a2.log_eps = plan->log_eps;
-    a2.out = out_dev; a2.ld_out = ld_out; a2.maxbuf = a.maxbuf; a2.flat = a.flat;
-    SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(fbank_logmel16_kernel), V2_LDS_BYTES));
-    SdProfScope prof(SD_PROF_FBANK, stream, (double)B * ((double)n * 4.0 + (double)T * plan->n_mels * 4.0));
-    hipLaunchKernelGGL(fbank_logmel16_kernel, dim3((unsigned)blocks), dim3(256), V2_LDS_BYTES, stream, a2);
+    hipLaunchKernelGGL(fbank_logmel_kernel, dim3((unsigned)blocks), dim3(256), V2_LDS_BYTES, stream, a);
   }
   SD_CHECK_LAUNCH("fbank_logmel_kernel");
   const int use_floor = plan->log_mode == SD_LOG_DB_TOPDB && plan->top_db >= 0.f;
