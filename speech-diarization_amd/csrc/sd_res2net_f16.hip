@@ -11,8 +11,10 @@
 // every workgroup) stream from global memory straight into the A-operand registers.
 //   * v_mfma_f32_16x16x32_f16 with the WEIGHTS as the A operand: accumulator rows are output channels, columns are
 //     time rows, so a lane ends up with 4 consecutive channels of one time row: 8-byte LDS accesses in the epilogue.
-//   * 8 MFMA waves = 4 channel groups of 32 x 2 halves of the time tiles; per K step of 32 a wave loads 2 weight
-//     fragments and <= 7 activation fragments for <= 14 MFMAs (LDS read rate 125 B/clk per CU at full matrix rate).
+//   * 8 MFMA waves = 8 channel groups of 16, each over ALL time tiles: per K step of 32 a wave loads one weight
+//     fragment and <= 14 activation fragments for as many MFMAs, so a conv's 96 KB of weights enter the CU once
+//     (with 4 channel groups x 2 time halves they entered twice, 192 KB per conv at ~18 B/clk = 10.7 k cycles, twice
+//     the matrix time); the price is every wave reading every activation fragment (1 KB of LDS per MFMA).
 //   * Three LDS buffers: u_j (being read), the next chunk c_{j+1} (turned into u_{j+1} = c_{j+1} + y_j in place by
 //     the epilogue, same rounding as the unfused path: f16(y_f32 + c)), and a staging copy of y_j.
 //   * Two more waves do every long-latency memory operation: one DMAs chunk j + 2 into the buffer conv j has finished
@@ -41,7 +43,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int RC_MAXN = 7;        // convs per chain (res2net_scale - 1)
-constexpr int RC_NT = 7;          // most 16-row time tiles per wave (the kernel is instantiated for 1..7)
+constexpr int RC_NT = 14;         // most 16-row time tiles of a segment (the kernel is instantiated for 1..14)
 constexpr int RC_CH = 128;        // channels per chunk
 constexpr int RC_ROWB = RC_CH * 2;
 constexpr int RC_THREADS = 704;   // 8 MFMA waves + a DMA wave + 2 copy-out waves
@@ -78,9 +80,9 @@ __device__ unsigned long long sd_res2_stamp_buf[4096 * 32];
 #define RC_T(i) do { } while (0)
 #endif
 
-// NT: time tiles per MFMA wave = ceil(ceil(T / 16) / 2): the tile loops carry no run-time bounds (a branch per tile cut
-// the K loop into read -> wait -> 2 MFMAs blocks, 2.5x the time of the pipe); the second half's surplus tile re-reads
-// clamped rows and is dropped in the epilogue.
+// NT = ceil(T / 16) time tiles: the tile loops carry no run-time bounds (a branch per tile cut the K loop into
+// read -> wait -> MFMA blocks, 2.5x the time of the pipe); the last tile's rows past T re-read clamped rows and are
+// dropped in the epilogue.
 template <int NT>
 __global__ __launch_bounds__(RC_THREADS) void res2net_chain_f16_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,16 +149,14 @@ __global__ __launch_bounds__(RC_THREADS) void res2net_chain_f16_kernel(const Cha
     return;
   }
 
-  // -------------------------------------------------------------------- MFMA waves
-  const int w_ch = wid & 3, w_t = wid >> 2;
+  // -------------------------------------------------------------------- MFMA waves: wave w owns channels 16 w .. 16 w + 15, all rows
   const int fr = lane & 15, fq = lane >> 4;
-  const int tile0 = w_t * NT;
-  // epilogue addressing: channels 32 w_ch + 16 ct + 4 fq + (0..3) of row t -> 8 bytes at chunk 4 w_ch + 2 ct + (fq >> 1)
-  const int ep_chunk0 = 4 * w_ch + (fq >> 1), ep_sub = 8 * (fq & 1);
-  const int ch0 = 32 * w_ch + 4 * fq;
+  // epilogue addressing: channels 16 w + 4 fq + (0..3) of row t -> 8 bytes at chunk 2 w + (fq >> 1)
+  const int ep_chunk0 = 2 * wid + (fq >> 1), ep_sub = 8 * (fq & 1);
+  const int ch0 = 16 * wid + 4 * fq;
 
-  const size_t w_off = ((size_t)(32 * w_ch + fr) * 3) * RC_CH + 8 * fq;      // this lane's row of the packed [cout][3][128] weights
-  h8 wa[RC_PF + 1][2];                                 // weight fragments in flight (rotating, 12 % (RC_PF + 1) == 0)
+  const size_t w_off = ((size_t)(16 * wid + fr) * 3) * RC_CH + 8 * fq;       // this lane's row of the packed [cout][3][128] weights
+  h8 wa[RC_PF + 1];                                    // weight fragments in flight (rotating, 12 % (RC_PF + 1) == 0)
   static_assert(12 % (RC_PF + 1) == 0, "the fragment ring must line up across convs");
 #ifdef SD_STAMP
   unsigned long long tacc[5] = {0, 0, 0, 0, 0};
@@ -172,41 +172,35 @@ __global__ __launch_bounds__(RC_THREADS) void res2net_chain_f16_kernel(const Cha
     const char* cur = smem + (j & 1) * BUF;
     char* nxt = smem + ((j + 1) & 1) * BUF;
     const _Float16* Wj = a.w[j - 1] + w_off;
-    f32x4v acc[NT][2];
+    f32x4v acc[NT];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[tt][ct][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[tt][r] = 0.f;
 
     if (j == 1) {
 #pragma unroll
-      for (int q = 0; q < RC_PF; ++q) {
-        wa[q][0] = *reinterpret_cast<const h8*>(Wj + (q >> 2) * RC_CH + (q & 3) * 32);
-        wa[q][1] = *reinterpret_cast<const h8*>(Wj + 16 * 3 * RC_CH + (q >> 2) * RC_CH + (q & 3) * 32);
-      }
+      for (int q = 0; q < RC_PF; ++q) wa[q] = *reinterpret_cast<const h8*>(Wj + (q >> 2) * RC_CH + (q & 3) * 32);
     }
     // K steps of 32: tap = q / 4, channels 32 (q % 4) ...  All NT activation fragments of a step are read before its MFMAs
-    // (scheduling barriers keep hipcc from re-serialising them into read -> wait -> 2 MFMAs with one read in flight,
-    // which ran the chain at 2x the time of the matrix pipe); the SIMD's other wave covers the first read's latency.
+    // (scheduling barriers keep hipcc from re-serialising them into read -> wait -> MFMA with one read in flight, which
+    // ran the chain at 2x the time of the matrix pipe); the SIMD's other wave covers the first read's latency.
     int base[NT];                                      // LDS address of this lane's k chunk fq of the gathered row, per tile
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
       {                                                // weights: RC_PF steps ahead; past this conv's last step: the next conv's first
         const int qq = (q + RC_PF) % 12;
         const _Float16* Wn = q + RC_PF < 12 || j >= n ? Wj : a.w[j] + w_off;
-        wa[(q + RC_PF) % (RC_PF + 1)][0] = *reinterpret_cast<const h8*>(Wn + (qq >> 2) * RC_CH + (qq & 3) * 32);
-        wa[(q + RC_PF) % (RC_PF + 1)][1] = *reinterpret_cast<const h8*>(Wn + 16 * 3 * RC_CH + (qq >> 2) * RC_CH + (qq & 3) * 32);
+        wa[(q + RC_PF) % (RC_PF + 1)] = *reinterpret_cast<const h8*>(Wn + (qq >> 2) * RC_CH + (qq & 3) * 32);
       }
       if ((q & 3) == 0) {
         const int delta = ((q >> 2) - 1) * a.dil;
         int frq = fr;
-        asm volatile("" : "+v"(frq));                  // opaque per tap: the 84 gather addresses of a conv are not loop
-                                                       // invariants to be hoisted out of the chain loop and spilled
+        asm volatile("" : "+v"(frq));                  // opaque per tap: a conv's gather addresses are not loop invariants
+                                                       // to be hoisted out of the chain loop and spilled
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-          int tr = (tile0 + tt) * 16 + frq;
+          int tr = tt * 16 + frq;
           tr = (tr < T ? tr : T - 1) + delta;
           tr = tr < 0 ? -tr : tr;
           tr = tr >= T ? 2 * (T - 1) - tr : tr;
@@ -219,56 +213,52 @@ __global__ __launch_bounds__(RC_THREADS) void res2net_chain_f16_kernel(const Cha
         xb[tt] = *reinterpret_cast<const h8*>(cur + (base[tt] ^ ((q & 3) << 6)));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[q % (RC_PF + 1)][0], xb[tt], acc[tt][0], 0, 0, 0);
-        acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[q % (RC_PF + 1)][1], xb[tt], acc[tt][1], 0, 0, 0);
-      }
+      for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[q % (RC_PF + 1)], xb[tt], acc[tt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // per-channel parameters of this lane's 2 x 4 channels: fetched here so the wait at the barrier covers their latency
-    f32x4v pb[2], ps[2], ph[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int c = ch0 + 16 * ct;
-      pb[ct] = a.bias[j - 1] ? *reinterpret_cast<const f32x4v*>(a.bias[j - 1] + c) : f32x4v{0.f, 0.f, 0.f, 0.f};
-      ps[ct] = a.scale[j - 1] ? *reinterpret_cast<const f32x4v*>(a.scale[j - 1] + c) : f32x4v{1.f, 1.f, 1.f, 1.f};
-      ph[ct] = a.shift[j - 1] ? *reinterpret_cast<const f32x4v*>(a.shift[j - 1] + c) : f32x4v{0.f, 0.f, 0.f, 0.f};
-    }
+    // per-channel parameters of this lane's 4 channels: fetched here so the wait at the barrier covers their latency
+    const f32x4v pb = a.bias[j - 1] ? *reinterpret_cast<const f32x4v*>(a.bias[j - 1] + ch0) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    const f32x4v ps = a.scale[j - 1] ? *reinterpret_cast<const f32x4v*>(a.scale[j - 1] + ch0) : f32x4v{1.f, 1.f, 1.f, 1.f};
+    const f32x4v ph = a.shift[j - 1] ? *reinterpret_cast<const f32x4v*>(a.shift[j - 1] + ch0) : f32x4v{0.f, 0.f, 0.f, 0.f};
     RC_T(0);
     RC_ARRIVE(j, wid);
     rc_barrier();                                      // A(j)
     RC_ARRIVE(j, 10 + (wid == 0 ? 0 : 20));
     RC_T(1);
     const bool more = j < n;
-    int eo[NT];                                        // this lane's 8 bytes of each tile (channel tile 0; tile 1 is at ^ 32)
+    int fre = fr;
+    asm volatile("" : "+v"(fre));                      // opaque per conv (as in the K loop): not hoisted out of the chain loop
+    constexpr int EC = 4;                              // tiles per epilogue chunk (register budget: 168 with 11 waves)
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-      int t = (tile0 + tt) * 16 + fr;
-      t = t < T ? t : T - 1;
-      eo[tt] = t * RC_ROWB + ((ep_chunk0 ^ (t & 15)) << 4) + ep_sub;
-    }
+    for (int t0 = 0; t0 < NT; t0 += EC) {
+      int eo[EC];                                      // this lane's 8 bytes of each tile
+      h4 cn[EC];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      h4 cn[NT];
-      if (more) {
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) cn[tt] = *reinterpret_cast<const h4*>(nxt + (eo[tt] ^ (32 * ct)));
+      for (int i = 0; i < EC; ++i) {
+        if (t0 + i < NT) {
+          int t = (t0 + i) * 16 + fre;
+          t = t < T ? t : T - 1;
+          eo[i] = t * RC_ROWB + ((ep_chunk0 ^ (t & 15)) << 4) + ep_sub;
+          if (more) cn[i] = *reinterpret_cast<const h4*>(nxt + eo[i]);
+        }
       }
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        const bool live = (tile0 + tt) * 16 + fr < T;
-        float v[4];
+      for (int i = 0; i < EC; ++i) {
+        if (t0 + i < NT) {
+          const bool live = (t0 + i) * 16 + fr < T;
+          float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[tt][ct][r] + pb[ct][r], 0.f) * ps[ct][r] + ph[ct][r];
-        h4 y, u;
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t0 + i][r] + pb[r], 0.f) * ps[r] + ph[r];
+          h4 y, u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          y[r] = (_Float16)v[r];
-          u[r] = (_Float16)(v[r] + (more ? (float)cn[tt][r] : 0.f));
-        }
-        if (live) {
-          *reinterpret_cast<h4*>(buf_y + (eo[tt] ^ (32 * ct))) = y;
-          if (more) *reinterpret_cast<h4*>(nxt + (eo[tt] ^ (32 * ct))) = u;
+          for (int r = 0; r < 4; ++r) {
+            y[r] = (_Float16)v[r];
+            u[r] = (_Float16)(v[r] + (more ? (float)cn[i][r] : 0.f));
+          }
+          if (live) {
+            *reinterpret_cast<h4*>(buf_y + eo[i]) = y;
+            if (more) *reinterpret_cast<h4*>(nxt + eo[i]) = u;
+          }
         }
       }
     }
@@ -297,7 +287,7 @@ extern "C" int sd_debug_read_res2_stamps(unsigned long long* out, int n) {
 extern "C" int sd_res2net_chain_supported(int T, int chunk, int n, int taps, int dil) {
   if (chunk != RC_CH || taps != 3 || n < 1 || n > RC_MAXN) return 0;
   if (T < 2 || dil < 1 || dil >= T) return 0;
-  if (((T + 15) >> 4) > 2 * RC_NT) return 0;
+  if (((T + 15) >> 4) > RC_NT) return 0;
   return 3 * ((T + 3) & ~3) * RC_ROWB <= RC_LDS_MAX;
 }
 
@@ -322,16 +312,14 @@ extern "C" int sd_res2net_chain_f16(void* r, int ld, int B, int T, const sd_laye
   }
   if (B == 0) return SD_OK;
   const int lds = 3 * ((T + 3) & ~3) * RC_ROWB;
-  const int nt = (((T + 15) >> 4) + 1) / 2;                    // time tiles per MFMA wave
+  const int nt = (T + 15) >> 4;                                // 16-row time tiles
   void (*kern)(const ChainArgs) = nullptr;
   switch (nt) {
-    case 1: kern = res2net_chain_f16_kernel<1>; break;
-    case 2: kern = res2net_chain_f16_kernel<2>; break;
-    case 3: kern = res2net_chain_f16_kernel<3>; break;
-    case 4: kern = res2net_chain_f16_kernel<4>; break;
-    case 5: kern = res2net_chain_f16_kernel<5>; break;
-    case 6: kern = res2net_chain_f16_kernel<6>; break;
-    default: kern = res2net_chain_f16_kernel<7>; break;
+#define RC_CASE(N_) case N_: kern = res2net_chain_f16_kernel<N_>; break;
+    RC_CASE(1) RC_CASE(2) RC_CASE(3) RC_CASE(4) RC_CASE(5) RC_CASE(6) RC_CASE(7)
+    RC_CASE(8) RC_CASE(9) RC_CASE(10) RC_CASE(11) RC_CASE(12) RC_CASE(13)
+#undef RC_CASE
+    default: kern = res2net_chain_f16_kernel<14>; break;
   }
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), RC_LDS_MAX));
   {
