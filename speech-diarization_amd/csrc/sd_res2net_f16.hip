@@ -23,14 +23,13 @@
 //     none of their waits ever sits behind an HBM round trip (vmcnt is in order; a wait after a store waits for its
 //     acknowledgement: with one wave doing both, the chain ran at a quarter of the matrix rate).
 //   * Two workgroup barriers per conv: A (K loop done, c_{j+1} landed) and B (u_{j+1} and the y_j staging complete).
-// Measured (MI355X, 5000 segments of T = 201, tools/stamp_res2.py): 1.6 ms per block against 1.3 ms for the seven
-// launches it replaces, i.e. no faster yet, with 21 fewer launches per forward and tdnn1 freed of its tee epilogue
-// (the f16 step as a whole is unchanged).  Per conv a workgroup spends ~14 k cycles where the matrix pipe needs 5.4 k:
-//   * weights: every workgroup streams each conv's 96 KB twice (both time halves) = 192 KB per conv through the CU's
-//     vector-memory path, which sustains ~18 B/clk in this mix: ~10.7 k cycles.  Two segments per workgroup would halve
-//     it, but two segments' buffers (4 x 51 KB) do not fit the LDS.
-//   * HBM: 51 KB in + 51 KB out per conv and segment is 3.6 GB per block = 0.7 ms at 5 TB/s: the floor of ANY schedule
-//     (the unfused path moves twice that); the copy-out waves need ~12 k cycles per conv at that rate.
+// Measured (MI355X, 5000 segments of T = 201, tools/time_chain.py, tools/stamp_res2.py): 1.47-1.59 ms per block (run to
+// run) against 1.3 ms for the seven launches it replaces: not faster by itself, but 21 fewer launches per forward, half
+// the HBM traffic (3.6 GB per block, 0.7 ms at 5 TB/s is the floor of ANY schedule) and tdnn1 freed of its tee epilogue
+// (the f16 step as a whole gained 1 %).  Per conv a workgroup spends ~13 k cycles where the matrix pipe needs 5 k
+// (stamps): K loop 10 k on the older waves / 13 k on the younger ones (with every wave reading every activation
+// fragment the LDS pipe is as loaded as the matrix pipe), epilogue 3.6 k, barrier skew.  What would change the picture
+// is two segments per workgroup (weights and barriers amortised), which two segments' buffers (6 x 51 KB) do not allow.
 // LDS image of a buffer: rows of 256 bytes, 16-byte chunk q of row t stored at chunk q ^ (t & 15): the fragment reads
 // (16 lanes = 16 consecutive rows, one chunk) and the epilogue's 8-byte accesses are bank-conflict free, and the DMA
 // fills it by permuting its per-lane SOURCE address.
