@@ -67,8 +67,8 @@ def deinterleave(gathered: torch.Tensor, n: int, world_size: int) -> torch.Tenso
 def all_gather_embeddings(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """local: this rank's [len(shard_indices), D] embeddings -> every rank gets the full [n_total, D], original order."""
     rank, w = world()
-    if w == 1:
-        return local[:n_total]
+    if w == 1 and not (dist.is_available() and dist.is_initialized() and os.environ.get("SD_DIST_FORCE_COLLECTIVE") == "1"):
+        return local[:n_total]          # (SD_DIST_FORCE_COLLECTIVE=1: run the collective even in a world of one, for tests)
     rows = shard_rows(n_total, w)
     d = local.shape[1]
     send = torch.zeros((rows, d), dtype=local.dtype, device=local.device)

@@ -166,3 +166,34 @@ def test_config4_affinity_50k_properties(dev):
     sub = x[:2000].cpu().numpy()
     from sklearn.metrics.pairwise import cosine_similarity
     assert np.abs(K[:2000, :2000].cpu().numpy() - cosine_similarity(sub)).max() < 2e-6
+
+
+def test_rccl_all_gather_executes_on_the_device(tmp_path):
+    """The build box has one GPU, so RCCL cannot be given two ranks here (it refuses two ranks per device); what CAN run is
+    the real thing in a world of one: `init_from_env("nccl")` with `device_id`, then the same `all_gather_into_tensor`
+    call the N-GPU job makes, on device tensors, through the sharded product entry (bench.py's step) — in a fresh process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import os, sys
+sys.path.insert(0, {root!r})
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", SD_DIST_FORCE_COLLECTIVE="1")
+import torch, torch.distributed as tdist
+from speech_diarization_amd import dist as sd
+torch.cuda.set_device(0)
+tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert tdist.get_backend() == "nccl"
+x = torch.arange(7 * 192, dtype=torch.float32, device="cuda").view(7, 192)
+full = sd.all_gather_embeddings(x, 7)            # the collective runs (forced) and the de-interleave is the identity
+torch.cuda.synchronize()
+assert full.is_cuda and torch.equal(full, x)
+t = torch.tensor([3.5], dtype=torch.float64, device="cuda")
+tdist.all_reduce(t, op=tdist.ReduceOp.MAX)      # bench.py's max-over-ranks timing
+assert float(t.item()) == 3.5
+tdist.barrier(); tdist.destroy_process_group()
+print("ok")
+"""
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), (res.stdout[-500:], res.stderr[-2000:])
