@@ -1,4 +1,6 @@
 // Error reporting, library identity and the N x N cosine-affinity entry point.
+#include <cstdlib>
+
 #include "sd_common.h"
 #include <atomic>
 #include <mutex>
@@ -141,6 +143,10 @@ extern "C" int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row
   a.M = row_hi - row_lo; a.T = 1;
   a.cin = Dp; a.cin_pad = Dp; a.cout = N; a.taps = 1; a.dil = 1;
   a.act = SD_ACT_NONE; a.act2 = SD_ACT_NONE;
+  // the whole matrix: tiles on and above the diagonal, each stored as is and transposed (half the MFMA work;
+  // K[i][j] and K[j][i] are then the same bits).  SD_AFFINITY_SYM=0 (diagnostic) computes every tile.
+  static const bool sym = [] { const char* e = getenv("SD_AFFINITY_SYM"); return !e || atoi(e) != 0; }();
+  if (sym && row_lo == 0 && row_hi == N) return sd_conv1d_cl_f32_symmetric(&a, stream);
   return sd_conv1d_cl_f32(&a, stream);
 }
 

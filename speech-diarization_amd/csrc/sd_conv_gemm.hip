@@ -49,7 +49,8 @@ __device__ unsigned long long sd_c32_stamp_buf[8192 * 10];
 // permuted at the source, chunk c of row r living at position c ^ ((r >> 1) & 7): the fragment reads of 16
 // consecutive rows then hit 16 different bank groups.
 template <bool DMA>
-__device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int vec, const int tile_m, const int tile_n, float* smem) {
+__device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int vec, const int tile_m, const int tile_n, float* smem,
+                                              const bool mirror = false) {
 #ifdef SD_STAMP
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
@@ -268,6 +269,30 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
   const unsigned long long t_e2 = __builtin_amdgcn_s_memtime();
 #endif
   sd_store_tile<float, BM, BN, 256>(p, Cs, LDC, m0, n0, tid, vec);
+  if (mirror && tile_m != tile_n) {
+    // symmetric product (x = w, the affinity): the tile below the diagonal is this tile transposed, written
+    // from the same LDS image.  8 lanes cover one 128-byte line of an output row (32 consecutive m), a wave
+    // instruction writes 8 rows; the 4 LDS reads behind a store are 2-way conflicted at most.
+    float* const Y = static_cast<float*>(p.y);
+    const int r4 = wid * 32 + (lane & 7) * 4;
+    const int mrow = m0 + r4;
+#pragma unroll 4
+    for (int c = lane >> 3; c < BN; c += 8) {
+      const int n = n0 + c;
+      if (n >= p.cout || mrow >= p.M) continue;
+      float* dst = Y + (size_t)n * p.ldo + p.o_col0 + mrow;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = Cs[(r4 + i) * LDC + c];
+      if (vec && mrow + 3 < p.M) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (mrow + i < p.M) dst[i] = v[i];
+      }
+    }
+  }
 #ifdef SD_STAMP
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long t_e3 = __builtin_amdgcn_s_memtime();
@@ -298,25 +323,46 @@ template <bool DMA>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_args p, const int vec, const int order, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_tiles = (p.cout + BN - 1) / BN;
-  if (order == 0) {
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-      conv_tile_f32<DMA>(p, vec, t / n_tiles, t % n_tiles, smem);
-      __syncthreads();              // the next tile refills the LDS stage the epilogue was reading
-    }
-    return;
-  }
   const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7;
   const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;   // this XCD's logical tiles
-  const int count = q + (xcd < r ? 1 : 0);
   const int peers = ((int)gridDim.x - xcd + 7) >> 3;                          // workgroups dealt to this XCD
   const int m_tiles = ntiles / n_tiles;
-  for (int i = blockIdx.x >> 3; i < count; i += peers) {
-    const int wg = first + i;
-    const int band = wg / (8 * n_tiles);
-    const int in_band = wg - band * 8 * n_tiles;
-    const int rows = m_tiles - band * 8 < 8 ? m_tiles - band * 8 : 8;
-    conv_tile_f32<DMA>(p, vec, band * 8 + in_band % rows, in_band / rows, smem);
-    __syncthreads();
+  const int start = order == 0 ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
+  const int count = order == 0 ? ntiles : q + (xcd < r ? 1 : 0);
+  const int step = order == 0 ? (int)gridDim.x : peers;
+  for (int i = start; i < count; i += step) {      // (one call site: the tile body is inlined once)
+    int tm, tn;
+    bool mirror = false;
+    if (order == 0) {
+      tm = i / n_tiles;
+      tn = i - tm * n_tiles;
+    } else if (order == 2) {
+      // symmetric product (M == cout, x == w): bands of 8 tile rows as below, but a band starts at its own diagonal
+      // block (columns 8 b .. n_tiles - 1); entries under the diagonal of that first block are skipped, every
+      // other tile is also written transposed.  Band b holds rows(b) * (n_tiles - 8 b) list entries;
+      // entries before band b: 8 * (b * n_tiles - 4 b (b - 1))  (all bands before b are full)
+      const int wg = first + i;
+      const float h = (float)(2 * n_tiles + 8);
+      int b = (int)((h - sqrtf(fmaxf(h * h - 8.f * (float)wg, 0.f))) * (1.f / 16.f));
+      b = b < 0 ? 0 : b;
+      while (b > 0 && 8 * (b * n_tiles - 4 * b * (b - 1)) > wg) --b;
+      while (8 * (b + 1) < n_tiles && 8 * ((b + 1) * n_tiles - 4 * (b + 1) * b) <= wg) ++b;
+      const int in_band = wg - 8 * (b * n_tiles - 4 * b * (b - 1));
+      const int rows = n_tiles - b * 8 < 8 ? n_tiles - b * 8 : 8;
+      tm = b * 8 + in_band % rows;
+      tn = b * 8 + in_band / rows;
+      if (tn < tm) continue;                                                   // uniform
+      mirror = true;
+    } else {
+      const int wg = first + i;
+      const int band = wg / (8 * n_tiles);
+      const int in_band = wg - band * 8 * n_tiles;
+      const int rows = m_tiles - band * 8 < 8 ? m_tiles - band * 8 : 8;
+      tm = band * 8 + in_band % rows;
+      tn = in_band / rows;
+    }
+    conv_tile_f32<DMA>(p, vec, tm, tn, smem, mirror);
+    __syncthreads();              // the next tile refills the LDS stage the epilogue was reading
   }
 }
 
@@ -423,7 +469,15 @@ extern "C" int sd_set_tuning(int key, long value) {
   return sd_set_error(SD_ERR_ARG, "sd_set_tuning: unknown key %d", key);
 }
 
-extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
+static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool symmetric);
+
+extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) { return conv1d_cl_f32_impl(a, stream, false); }
+
+// x == w, M == cout, no epilogue arithmetic: only the tiles on and above the diagonal are computed, each is stored
+// twice (as is and transposed).  Internal (sd_common.h): the affinity's full-matrix call.
+int sd_conv1d_cl_f32_symmetric(const sd_conv_args* a, sd_stream_t stream) { return conv1d_cl_f32_impl(a, stream, true); }
+
+static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool symmetric) {
   SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_f32: null args");
   SD_CHECK_ARG(a->w_dtype == SD_DT_F32, "sd_conv1d_cl_f32: w_dtype %d not supported by the f32 operator", a->w_dtype);
   SD_CHECK_ARG(a->x && a->w && a->y, "sd_conv1d_cl_f32: null x/w/y");
@@ -462,6 +516,10 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
   const long tiles_n = (a->cout + BN - 1) / BN;
   SD_CHECK_ARG(tiles_m * tiles_n < (1L << 31), "sd_conv1d_cl_f32: grid too large");
   // fewer 128x128 tiles than half the CUs: 32x32 tiles with in-workgroup split-K (sd_set_tuning / SD_SKINNY_TILES)
+  if (symmetric)
+    SD_CHECK_ARG(a->M == a->cout && a->T == 1 && a->taps == 1 && !a->bias && !a->scale && !a->shift && !a->tee && !a->colstat &&
+                 a->act == SD_ACT_NONE && a->act2 == SD_ACT_NONE && a->cout <= a->ldo - a->o_col0,
+                 "sd_conv1d_cl_f32_symmetric: needs a square plain product (M=%d cout=%d)", a->M, a->cout);
   const long skinny_below = g_skinny_below.load(std::memory_order_relaxed);
   if (!a->colstat && tiles_m * tiles_n < skinny_below) {
     const long g = (long)((a->M + SK_T - 1) / SK_T) * ((a->cout + SK_T - 1) / SK_T);
@@ -492,14 +550,20 @@ extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) {
   {
     SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream),
                      2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
-    const long ntiles = tiles_m * tiles_n;
+    long ntiles = tiles_m * tiles_n;
+    int ord = order;
+    if (symmetric && tiles_n >= 2) {                      // the list of band entries (see the kernel)
+      ntiles = 0;
+      for (long b = 0; 8 * b < tiles_n; ++b) ntiles += (tiles_n - 8 * b < 8 ? tiles_n - 8 * b : 8) * (tiles_n - 8 * b);
+      ord = 2;
+    }
     const long grid = (persist > 0 && ntiles > persist) ? persist : ntiles;
     if (dma)
       hipLaunchKernelGGL(conv_gemm_f32_kernel<true>, dim3((unsigned)grid), dim3(256), lds,
-                         static_cast<hipStream_t>(stream), *a, vec, order, (int)ntiles);
+                         static_cast<hipStream_t>(stream), *a, vec, ord, (int)ntiles);
     else
       hipLaunchKernelGGL(conv_gemm_f32_kernel<false>, dim3((unsigned)grid), dim3(256), lds,
-                         static_cast<hipStream_t>(stream), *a, vec, order, (int)ntiles);
+                         static_cast<hipStream_t>(stream), *a, vec, ord, (int)ntiles);
   }
   SD_CHECK_LAUNCH("conv_gemm_f32_kernel");
   return SD_OK;
