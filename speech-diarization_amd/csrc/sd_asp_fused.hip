@@ -24,6 +24,7 @@ namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int AK = 128;       // attention channels = K of the logits GEMM
 constexpr int WLD = AK + 8;   // LDS row stride of the weight tile in halves (272 B: conflict-free ds_read_b128)
@@ -32,7 +33,7 @@ constexpr int NG = CPB / 16;  // channel groups of 16 (one MFMA row tile)
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
 
 // reduction over the 16 lanes of a DPP row; every lane of the row ends up with the result
@@ -47,24 +48,41 @@ __device__ __forceinline__ float red16(float v) {
   return v;
 }
 
+// 16-lane (DPP row) reduction of FOUR registers at once, one instruction per register and step: dependent steps are
+// three instructions apart (a DPP read needs two wait states behind the VALU write of its source); every lane of a
+// row ends up with the row's result.  (Written out because hipcc pairs up the builtin form into v_mov_b32_dpp x 2 +
+// v_pk_add_f32, and canonicalises the operands of a max: 1.5 and 4 instructions per step instead of 1.)
+#define SD_DPP_STEP4(op, ctrl)                                              \
+  op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                  \
+  op " %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                  \
+  op " %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                  \
+  op " %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+#define SD_DPP_RED4(op, a, b, c, d)                                                                              \
+  asm volatile("s_nop 1\n\t" SD_DPP_STEP4(op, "quad_perm:[1,0,3,2]") SD_DPP_STEP4(op, "quad_perm:[2,3,0,1]")     \
+               SD_DPP_STEP4(op, "row_half_mirror") SD_DPP_STEP4(op, "row_mirror") "s_nop 1"                        \
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
 template <int TPW>   // 16-frame tiles per wave: T <= 64 * TPW
 __global__ __launch_bounds__(256, 3) void asp_attend_pool_f16_kernel(const _Float16* __restrict__ a1, const _Float16* __restrict__ wc,
                                                                      const _Float16* __restrict__ h, int ldh, int Tn, int C,
                                                                      float eps, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 sw[];   // [CPB / 2][WLD] weights; reused for the partial statistics
+  extern __shared__ __attribute__((aligned(16))) _Float16 sw[];   // [CPB / 2][WLD] weights, then the partial statistics
   const int cblocks = C / CPB;
   const int b = blockIdx.x / cblocks, cblk = blockIdx.x % cblocks;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, quad = lane >> 4;      // MFMA column (frame) / k group and output row group
 
-  // this wave's frames: B fragments for the whole kernel.  lane (col, quad) holds a1[t0 + 16 j + col][32 ks + 8 quad .. +7]
-  const int t0 = wid * TPW * 16;
+  // this wave's frames: 16-frame tiles wid, wid + 4, wid + 8, ... (slot j = tile 4 j + wid), so that the tiles past T
+  // fall into the LAST slot of some waves, which those waves skip (T = 201: 13 tiles; wave 0 runs 4 slots, the others 3).
+  // B fragments for the whole kernel: lane (col, quad) holds a1[t0 + 64 j + col][32 ks + 8 quad .. +7]
+  const int t0 = wid * 16;
+  const bool full = ((TPW - 1) * 4 + __builtin_amdgcn_readfirstlane(wid)) * 16 < Tn;    // wave-uniform: the last slot has live frames
   h8 af[TPW][AK / 32];
   {
     const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-      const int t = t0 + j * 16 + col;
+      const int t = t0 + j * 64 + col;
       const _Float16* ar = a1 + ((size_t)b * Tn + (t < Tn ? t : 0)) * AK + quad * 8;
 #pragma unroll
       for (int ks = 0; ks < AK / 32; ++ks) af[j][ks] = t < Tn ? *reinterpret_cast<const h8*>(ar + ks * 32) : z;
@@ -82,80 +100,117 @@ __global__ __launch_bounds__(256, 3) void asp_attend_pool_f16_kernel(const _Floa
   stage_w(0);
   __syncthreads();
 
-  // h pointer of this lane: frame t0 + col (+16 j), channels cblk*256 + 16 g + 4 quad .. +3
-  const _Float16* hl = h + ((size_t)b * Tn + t0 + col) * ldh + (size_t)cblk * CPB + 4 * quad;
+  // h of this lane.  A 16-channel MFMA row tile may be ANY 16 channels, so the tiles are chosen for the loads: groups
+  // 2 p and 2 p + 1 share the 32 channels [32 p, 32 p + 32) as  channel(2 p + e, tile row 4 q + r) = 32 p + 8 q + 4 e + r.
+  // Lane (frame col, quad) then needs channels 32 p + 8 quad .. + 7 for the pair: ONE 16-byte load per frame and pair,
+  // a wave instruction reads 64 contiguous bytes of 16 rows (8-byte loads per group fetched every 128-byte line four
+  // times from L2: the L1 is smaller than what the CU's twelve waves have in flight).
+  const _Float16* hl = h + ((size_t)b * Tn + t0 + col) * ldh + (size_t)cblk * CPB + 8 * quad;
   bool live[TPW];
 #pragma unroll
-  for (int j = 0; j < TPW; ++j) live[j] = t0 + j * 16 + col < Tn;
-  const h4 hz = {0, 0, 0, 0};
-  auto load_h = [&](int g, h4* dst) {
+  for (int j = 0; j < TPW; ++j) live[j] = t0 + j * 64 + col < Tn;
+  const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto load_h = [&](int p, h8* dst) {
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) dst[j] = live[j] ? *reinterpret_cast<const h4*>(hl + (size_t)j * 16 * ldh + g * 16) : hz;
+#ifdef SD_ASP_NOH
+    for (int j = 0; j < TPW; ++j) dst[j] = h8{(_Float16)(float)p, (_Float16)1.f, (_Float16)(float)j, (_Float16)2.f, (_Float16)1.f, (_Float16)0.5f, (_Float16)3.f, (_Float16)2.f};
+#else
+    for (int j = 0; j < TPW; ++j) dst[j] = live[j] ? *reinterpret_cast<const h8*>(hl + (size_t)j * 64 * ldh + p * 32) : hz;
+#endif
   };
 
-  // per-wave partial statistics of channel 16 g + 4 quad + r: (max, sum w, sum w h, sum w h^2), kept by lane col == g % 16
-  float pm[4], pd[4], pn[4], pq[4];
-  h4 hv[TPW], hn[TPW];
-  load_h(0, hv);
-#pragma unroll 1
-  for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) load_h(g + 1, hn);
-    if (g == NG / 2) {
-      __syncthreads();              // every wave is done with the first half of the weights
-      stage_w(1);
-      __syncthreads();
-    }
-    // A fragment: lane (col, quad) holds W[16 g + col][32 ks + 8 quad .. +7]
-    const _Float16* wr = sw + ((g % (NG / 2)) * 16 + col) * WLD + quad * 8;
+  // per-wave partial statistics (max, sum w, sum w h, sum w h^2) per channel -> LDS behind the weights
+  float* const st = reinterpret_cast<float*>(sw + (CPB / 2) * WLD);     // [wave][channel][4]
+  // frames past T are masked inside the MFMA: the accumulators start at 0 (live) or -inf (dead; a1 is zero there, so
+  // the products are finite), and exp2(-inf) = 0 drops them from every sum.  Only the last slot can hold such frames
+  // (T > 64 (TPW - 1)).
+  f32x4 minit;
+  {
+    const float v = live[TPW - 1] ? 0.f : -INFINITY;
+    minit = f32x4{v, v, v, v};
+  }
+  constexpr float LOG2E = 1.4426950408889634f;
+  // one channel group.  VALU work per (frame, channel) is what bounds this kernel (measured: 2.8 ms with the h loads
+  // removed, 1.1 ms with the softmax removed as well), so: masks come out of the MFMA, the exponent is one packed
+  // FMA + v_exp_f32, the weighted sums run on packed f32 pairs (channels r, r + 1), and the 16-lane reductions are
+  // single DPP instructions (v_max_f32_dpp / v_add_f32_dpp).
+  auto group = [&](const int p, const int e, const h8 (&hv)[TPW]) {
+    // A fragment: lane (col, quad) holds the weights of tile row col = channel 32 p + 8 (col >> 2) + 4 e + (col & 3)
+    const _Float16* wr = sw + ((32 * p + 8 * (col >> 2) + 4 * e + (col & 3)) % (CPB / 2)) * WLD + quad * 8;
     f32x4 acc[TPW];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TPW; ++j) acc[j] = j == TPW - 1 ? minit : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < AK / 32; ++ks) {
       const h8 wf = *reinterpret_cast<const h8*>(wr + ks * 32);
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af[j][ks], acc[j], 0, 0, 0);
+      for (int j = 0; j < (TPW > 1 ? TPW - 1 : 1); ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af[j][ks], acc[j], 0, 0, 0);
     }
-    float m[4], d[4], n[4], q[4];
+    if (TPW > 1 && full) {          // (skipped: the slot's accumulators stay at -inf and drop out of max and sums)
+#pragma unroll
+      for (int ks = 0; ks < AK / 32; ++ks) {
+        const h8 wf = *reinterpret_cast<const h8*>(wr + ks * 32);
+        acc[TPW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af[TPW - 1][ks], acc[TPW - 1], 0, 0, 0);
+      }
+    }
+    float m[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float mx = -INFINITY;
+      float mx = acc[0][r];
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        acc[j][r] = live[j] ? acc[j][r] : -INFINITY;
-        mx = fmaxf(mx, acc[j][r]);
-      }
-      mx = red16<true>(mx);
-      const float base = mx == -INFINITY ? 0.f : mx;     // a wave whose frames are all past T: every w = exp(-inf) = 0
-      float dd = 0.f, nn = 0.f, qq = 0.f;
+      for (int j = 1; j < TPW; ++j) mx = fmaxf(mx, acc[j][r]);
+      m[r] = mx;
+    }
+    SD_DPP_RED4("v_max_f32_dpp", m[0], m[1], m[2], m[3]);     // max over the 16 frames of a DPP row
+    float d[4], n[4], q[4];
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const float w = __expf(acc[j][r] - base);
-        const float hh = (float)hv[j][r];
-        const float wh = w * hh;
+    for (int rp = 0; rp < 2; ++rp) {
+      // a wave whose frames are all past T: max = -inf, every w = exp2(-inf) = 0
+      const f32x2 nb = {m[2 * rp] == -INFINITY ? 0.f : -m[2 * rp] * LOG2E, m[2 * rp + 1] == -INFINITY ? 0.f : -m[2 * rp + 1] * LOG2E};
+      f32x2 dd = {0.f, 0.f}, nn = {0.f, 0.f}, qq = {0.f, 0.f};
+      auto slot = [&](const int j) {
+        const f32x2 x = {acc[j][2 * rp], acc[j][2 * rp + 1]};
+        const f32x2 ex = x * f32x2{LOG2E, LOG2E} + nb;
+        const f32x2 w = {__builtin_amdgcn_exp2f(ex[0]), __builtin_amdgcn_exp2f(ex[1])};
+        const f32x2 hh = {(float)hv[j][4 * e + 2 * rp], (float)hv[j][4 * e + 2 * rp + 1]};
+        const f32x2 wh = w * hh;
         dd += w;
         nn += wh;
         qq += wh * hh;
-      }
-      m[r] = mx; d[r] = red16<false>(dd); n[r] = red16<false>(nn); q[r] = red16<false>(qq);
-    }
-    if (col == (g & 15)) {
+      };
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { pm[r] = m[r]; pd[r] = d[r]; pn[r] = n[r]; pq[r] = q[r]; }
-    }
+      for (int j = 0; j < (TPW > 1 ? TPW - 1 : 1); ++j) slot(j);
+      if (TPW > 1 && full) slot(TPW - 1);
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) hv[j] = hn[j];
+      for (int k = 0; k < 2; ++k) { d[2 * rp + k] = dd[k]; n[2 * rp + k] = nn[k]; q[2 * rp + k] = qq[k]; }
+    }
+    SD_DPP_RED4("v_add_f32_dpp", d[0], d[1], d[2], d[3]);
+    SD_DPP_RED4("v_add_f32_dpp", n[0], n[1], n[2], n[3]);
+    SD_DPP_RED4("v_add_f32_dpp", q[0], q[1], q[2], q[3]);
+    if (col == 0) {                 // every lane of the row holds the row's results
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(st + ((size_t)wid * CPB + 32 * p + 8 * quad + 4 * e + r) * 4) = f32x4{m[r], d[r], n[r], q[r]};
+    }
+  };
+  h8 ha[TPW], hb[TPW];
+  load_h(0, ha);
+#pragma unroll 1
+  for (int p = 0; p < NG / 2; p += 2) {     // two pairs of groups per trip: the h registers swap roles instead of being copied
+    if (p == NG / 4) {
+      __syncthreads();              // every wave is done with the first half of the weights
+      stage_w(1);
+      __syncthreads();
+    }
+    load_h(p + 1, hb);
+    group(p, 0, ha);
+    group(p, 1, ha);
+    if (p + 2 < NG / 2) load_h(p + 2, ha);
+    group(p + 1, 0, hb);
+    group(p + 1, 1, hb);
   }
 
-  // merge the four waves: stats[wave][channel][4] in LDS (the weight tile is dead)
-  __syncthreads();
-  float* st = reinterpret_cast<float*>(sw);
-  {
-    // lane (col, quad) kept group g = col: channels 16 col + 4 quad + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<f32x4*>(st + ((size_t)wid * CPB + 16 * col + 4 * quad + r) * 4) = f32x4{pm[r], pd[r], pn[r], pq[r]};
-  }
+  // merge the four waves
   __syncthreads();
   {
     const int c = tid;   // 256 threads = 256 channels
@@ -185,8 +240,8 @@ __global__ __launch_bounds__(256, 3) void asp_attend_pool_f16_kernel(const _Floa
 template <int TPW>
 int launch_f16(const void* a1, const void* wc, const void* h, int ldh, int B, int T, int C, float eps, float* out, hipStream_t s) {
   auto kern = asp_attend_pool_f16_kernel<TPW>;
-  const size_t lds = (size_t)(CPB / 2) * WLD * sizeof(_Float16);
-  static_assert((size_t)(CPB / 2) * WLD * sizeof(_Float16) >= (size_t)4 * CPB * 4 * sizeof(float), "statistics must fit in the weight tile");
+  const size_t lds = (size_t)(CPB / 2) * WLD * sizeof(_Float16) + (size_t)4 * CPB * 4 * sizeof(float);   // 34 + 16 KB: three workgroups per CU
+  static_assert(3 * ((size_t)(CPB / 2) * WLD * sizeof(_Float16) + (size_t)4 * CPB * 4 * sizeof(float)) <= 160 * 1024, "three workgroups per CU");
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * (C / CPB))), dim3(256), lds, s, static_cast<const _Float16*>(a1),
                      static_cast<const _Float16*>(wc), static_cast<const _Float16*>(h), ldh, T, C, eps, out);
@@ -354,5 +409,6 @@ extern "C" int sd_asp_attend_pool_dt(const void* a1, const void* wc, const void*
   }
   if (T <= 64) return launch_f16<1>(a1, wc, h, ldh, B, T, C, eps, out, s);
   if (T <= 128) return launch_f16<2>(a1, wc, h, ldh, B, T, C, eps, out, s);
+  if (T <= 192) return launch_f16<3>(a1, wc, h, ldh, B, T, C, eps, out, s);     // (the kernel relies on T > 64 (TPW - 1))
   return launch_f16<4>(a1, wc, h, ldh, B, T, C, eps, out, s);
 }

@@ -89,7 +89,8 @@ def test_conv1d_cl_f16_wide_output_with_plain_tee(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
-@pytest.mark.parametrize("B,T,Cc", [(3, 201, 512), (2, 101, 256), (4, 33, 256), (2, 256, 256), (5, 1, 256), (2, 64, 768), (1, 129, 3072), (2, 208, 1024)])
+@pytest.mark.parametrize("B,T,Cc", [(3, 201, 512), (2, 101, 256), (4, 33, 256), (2, 256, 256), (5, 1, 256), (2, 64, 768), (1, 129, 3072), (2, 208, 1024),
+                                    (2, 150, 256), (2, 192, 256), (2, 193, 512), (2, 65, 256), (3, 16, 256), (2, 17, 256), (2, 240, 256)])
 def test_fused_attention_pooling_matches_f64(dev, B, T, Cc, dtype):
     """asp.conv + softmax over T + weighted mean/std in one kernel vs float64 on the same operands,
     and vs the two-operator path it replaces (which stores the logits in the activation dtype)."""
