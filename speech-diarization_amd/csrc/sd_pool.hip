@@ -362,6 +362,29 @@ __global__ __launch_bounds__(256) void split16_rows_kernel(const float* __restri
 
 }  // namespace
 
+// f32 -> f16 (round to nearest even), n % 8 == 0 elements, both 16-byte aligned: the features in front of the f16 stem
+__global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, long n8, _Float16* __restrict__ y) {
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+    h8v o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[k] = (_Float16)a[k]; o[4 + k] = (_Float16)b[k]; }
+    reinterpret_cast<h8v*>(y)[i] = o;
+  }
+}
+
+int sd_cast_f32_f16(const float* x, long n, void* y, sd_stream_t stream) {
+  SD_CHECK_ARG(n >= 0 && n % 8 == 0 && sd_aligned16(x) && sd_aligned16(y), "sd_cast_f32_f16: n=%ld must be a multiple of 8, pointers 16-byte aligned", n);
+  if (n == 0) return SD_OK;
+  const long n8 = n / 8;
+  const long blocks = (n8 + 255) / 256;
+  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, static_cast<hipStream_t>(stream), x, n8,
+                     static_cast<_Float16*>(y));
+  SD_CHECK_LAUNCH("cast_f32_f16_kernel");
+  return SD_OK;
+}
+
 extern "C" int sd_seg_mean_std_dt(const void* x, int x_dtype, int ld, int col0, int B, int T, int C, int want_std, float eps,
                                   float* out, sd_stream_t stream) {
   if (int e = check_cl_dt("sd_seg_mean_std_dt", x, x_dtype, ld, col0, C)) return e;
