@@ -334,36 +334,59 @@ __global__ __launch_bounds__(512, 2) void asp_attend_pool_f32_kernel(const float
     }
     // the next group's weight fragments load under the softmax phase (wf is dead from here on)
     if (g + 8 < ngroups) load_w(g + 8, wf);
-    f32x4 mu4, sd4;
+    // softmax over the frames + weighted mean / variance (two passes), four channels per lane: packed f32 pairs
+    // (channels r, r + 1), one FMA + v_exp_f32 per weight, single-instruction DPP reductions.  Frames past T are
+    // masked only in the tiles that can hold them (the dispatch guarantees T > 16 JMIN).
+    constexpr int JMIN = NT == 4 ? 0 : NT == 8 ? 4 : NT == 13 ? 8 : 13;
+    constexpr float LOG2E = 1.4426950408889634f;
+    float m[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        acc[j][r] = j * 16 + col < Tn ? acc[j][r] : -INFINITY;
+        if (j >= JMIN) acc[j][r] = j * 16 + col < Tn ? acc[j][r] : -INFINITY;
         mx = fmaxf(mx, acc[j][r]);
       }
-      mx = red16<true>(mx);
-      float dd = 0.f, nn = 0.f;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float w = __expf(acc[j][r] - mx);
-        acc[j][r] = w;
-        dd += w;
-        nn += w * hv[j][r];
-      }
-      dd = red16<false>(dd);
-      const float mu = red16<false>(nn) / dd;
-      float vv = 0.f;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float d = hv[j][r] - mu;
-        vv += acc[j][r] * d * d;
-      }
-      vv = red16<false>(vv);
-      mu4[r] = mu;
-      sd4[r] = sqrtf(fmaxf(vv / dd, eps));
+      m[r] = mx;
     }
+    SD_DPP_RED4("v_max_f32_dpp", m[0], m[1], m[2], m[3]);      // (finite: frame 0 of every segment is live)
+    float d[4], n[4], v[4];
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+      const f32x2 nb = {-m[2 * rp] * LOG2E, -m[2 * rp + 1] * LOG2E};
+      f32x2 dd = {0.f, 0.f}, nn = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const f32x2 e = f32x2{acc[j][2 * rp], acc[j][2 * rp + 1]} * f32x2{LOG2E, LOG2E} + nb;
+        const f32x2 w = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        acc[j][2 * rp] = w[0];
+        acc[j][2 * rp + 1] = w[1];
+        dd += w;
+        nn += w * f32x2{hv[j][2 * rp], hv[j][2 * rp + 1]};
+      }
+      d[2 * rp] = dd[0]; d[2 * rp + 1] = dd[1];
+      n[2 * rp] = nn[0]; n[2 * rp + 1] = nn[1];
+    }
+    SD_DPP_RED4("v_add_f32_dpp", d[0], d[1], d[2], d[3]);
+    SD_DPP_RED4("v_add_f32_dpp", n[0], n[1], n[2], n[3]);
+    f32x4 mu4, sd4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mu4[r] = n[r] / d[r];
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+      const f32x2 mu2 = {mu4[2 * rp], mu4[2 * rp + 1]};
+      f32x2 vv = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const f32x2 dl = f32x2{hv[j][2 * rp], hv[j][2 * rp + 1]} - mu2;
+        vv += f32x2{acc[j][2 * rp], acc[j][2 * rp + 1]} * (dl * dl);
+      }
+      v[2 * rp] = vv[0]; v[2 * rp + 1] = vv[1];
+    }
+    SD_DPP_RED4("v_add_f32_dpp", v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sd4[r] = sqrtf(fmaxf(v[r] / d[r], eps));
     if (col == 0) {
       float* o = out + (size_t)b * 2 * C + (size_t)cblk * cpb + g * 16 + 4 * quad;
       *reinterpret_cast<f32x4*>(o) = mu4;
