@@ -51,7 +51,7 @@ typedef void* sd_stream_t; /* hipStream_t */
 #define SD_ERR_WORKSPACE (-3)
 #define SD_ERR_HIP (-4)
 
-#define SD_ABI_VERSION 4
+#define SD_ABI_VERSION 5
 
 int sd_abi_version(void);
 const char* sd_last_error(void);
@@ -245,7 +245,8 @@ typedef struct {
  * sd_res2net_chain_supported: chunk == 128, taps == 3, 1 <= n <= 7, dilation < T <= 212 (three [T][128] f16 buffers
  * in the 160 KB LDS); the entry returns SD_ERR_UNSUPPORTED (nothing launched) otherwise. */
 int sd_res2net_chain_supported(int T, int chunk, int n, int taps, int dil);
-int sd_res2net_chain_f16(void* r, int ld, int B, int T, const sd_layer* layers, int n, sd_stream_t stream);
+size_t sd_res2net_chain_workspace_bytes(int n);     /* the n convs' weights in MFMA-fragment order (re-made by every call) */
+int sd_res2net_chain_f16(void* r, int ld, int B, int T, const sd_layer* layers, int n, void* ws, size_t ws_bytes, sd_stream_t stream);
 
 size_t sd_ecapa_workspace_bytes(const sd_ecapa_weights* w, int B, int T);
 

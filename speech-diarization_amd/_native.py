@@ -21,7 +21,7 @@ SD_DT_F32, SD_DT_F16 = 0, 1
 SD_TUNE_SKINNY_TILES = 1
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
-SD_ABI_VERSION = 4
+SD_ABI_VERSION = 5
 SD_PROF_CONV_GEMM, SD_PROF_FBANK = 0, 1
 
 
@@ -114,7 +114,8 @@ PROTOTYPES = {
     "sd_asp_attend_pool_supported": (_I, [_I, _I, _I, _I]),
     "sd_asp_attend_pool_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "sd_res2net_chain_supported": (_I, [_I, _I, _I, _I, _I]),
-    "sd_res2net_chain_f16": (_I, [_P, _I, _I, _I, C.POINTER(sd_layer), _I, _P]),
+    "sd_res2net_chain_workspace_bytes": (C.c_size_t, [_I]),
+    "sd_res2net_chain_f16": (_I, [_P, _I, _I, _I, C.POINTER(sd_layer), _I, _P, C.c_size_t, _P]),
     "sd_ecapa_forward_f16": (_I, [C.POINTER(sd_ecapa_weights), _P, _I, _I, _P, _P, _Z, _P]),
     "sd_seg_mean_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sd_seg_mean_std_f32": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),

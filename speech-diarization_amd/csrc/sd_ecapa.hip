@@ -33,6 +33,7 @@ struct Carver {
 
 struct Buffers {
   void *x0, *r, *t2, *xcat, *h, *s0, *s1, *a1, *e;   // activation dtype (e = attention logits)
+  void* wpk; size_t wpk_bytes;                        // Res2Net chain weights in fragment order (f16 path)
   float *semean, *seh, *gate, *stats, *gbias, *pooled;
   size_t bytes;
 };
@@ -61,6 +62,8 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.stats = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
   b.gbias = static_cast<float*>(c.take((size_t)B * w->att_channels, 4));
   b.pooled = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
+  b.wpk_bytes = act_dtype == SD_DT_F16 ? sd_res2net_chain_workspace_bytes(w->res2_scale - 1) : 0;
+  b.wpk = c.take(b.wpk_bytes, 1);
   b.a1 = b.x0;    // block-0 output is dead once block 1 has consumed it
   b.e = b.xcat;
   b.bytes = c.off;
@@ -182,7 +185,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       SD_TRY(run_conv(a, stream));
     }
     if (chain) {
-      SD_TRY(sd_res2net_chain_f16(b.r, C, B, T, blk.res2, w->res2_scale - 1, stream));
+      SD_TRY(sd_res2net_chain_f16(b.r, C, B, T, blk.res2, w->res2_scale - 1, b.wpk, b.wpk_bytes, stream));
     } else {
       for (int j = 1; j < w->res2_scale; ++j) {
         void* src = (j & 1) ? b.s0 : b.s1;

@@ -110,7 +110,9 @@ def res2net_chain(r: torch.Tensor, T: int, layers: list[dict]) -> torch.Tensor:
         L.cin, L.cin_pad, L.cout, L.taps, L.dil, L.w_dtype = d.get("cin", cin_pad), cin_pad, cout, taps, d["dil"], _dt(d["w"].dtype)
     B = r.shape[0] // T
     with torch.cuda.device(r.device):
-        N.check(lib.sd_res2net_chain_f16(r.data_ptr(), r.stride(0), B, T, arr, len(layers), _stream(r)), "sd_res2net_chain_f16")
+        ws_bytes = max(256, int(lib.sd_res2net_chain_workspace_bytes(len(layers))))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=r.device)
+        N.check(lib.sd_res2net_chain_f16(r.data_ptr(), r.stride(0), B, T, arr, len(layers), ws.data_ptr(), ws_bytes, _stream(r)), "sd_res2net_chain_f16")
     return r
 
 

@@ -23,4 +23,4 @@ print("  conv 3: arrival at barrier A relative to wave 0 entering the K loop, me
 print(f"  DMA wave after its vmcnt(0): {np.median(raw[:, 18] - raw[:, 11]):.0f}; barrier A released (wave 0): {np.median(raw[:, 10] - raw[:, 11]):.0f}")
 names = ["K loops (7)", "barrier A (7)", "epilogues (7)", "barrier B (7)", "prologue wait", "total"]
 print(f"B={B} T={T}: MFMA wave 0, median cycles per workgroup: " + "  ".join(f"{nm} {np.median(st[:, i]):.0f}" for i, nm in enumerate(names)))
-print("  (matrix pipe needs 7 x 12 x 14 x 16 x 2 waves = 37632 cycles per SIMD)")
+print("  (matrix pipe needs 7 convs x 24 steps x 7 tiles x 32 cycles = 37632 cycles per SIMD at one MFMA per 32 cycles)")
