@@ -16,7 +16,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int SHAPE>   // 0: v_mfma_f32_32x32x16_f16, 1: v_mfma_f32_16x16x32_f16
+template <int SHAPE>   // 0: v_mfma_f32_32x32x16_f16 (4 chains), 1: v_mfma_f32_16x16x32_f16 (8 chains), 2: 32x32x16 with 8 chains and 4 + 2 operand fragments (the 4 x 2 tile pattern of a conv wave)
 __global__ __launch_bounds__(256) void spin(const h8* __restrict__ ops, int iters, float* sink, unsigned long long* stamps) {
   const int tid = threadIdx.x;
   const h8 a = ops[tid & 63], b = ops[64 + (tid & 63)];
@@ -34,6 +34,29 @@ __global__ __launch_bounds__(256) void spin(const h8* __restrict__ ops, int iter
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) out += acc[i][0] + acc[i][15];
+  } else if (SHAPE == 2) {
+    f32x16 acc[4][2];
+    h8 fa[4], fb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = ops[(tid + i) & 63];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = ops[64 + ((tid + j) & 63)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) out += acc[i][j][0] + acc[i][j][15];
   } else {
     f32x4 acc[8];
 #pragma unroll
@@ -64,6 +87,7 @@ int main() {
   CHECK(hipMalloc(&stamps, (size_t)max_blocks * 4 * 2 * sizeof(unsigned long long)));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spin<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spin<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spin<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
@@ -71,18 +95,20 @@ int main() {
   for (int random = 0; random < 2; ++random) {
     for (auto& v : host) v = (_Float16)(random ? (float)(rand() % 2001 - 1000) / 1000.f : 0.f);
     CHECK(hipMemcpy(ops, host.data(), host.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-    for (int shape = 0; shape < 2; ++shape) {
+    for (int shape = 0; shape < 3; ++shape) {
       for (int wps : {1, 2, 4}) {
+        if (shape == 2 && wps == 4) continue;              // 140 registers: two waves per SIMD
         const int chains = shape == 0 ? 4 : 8;
-        const int iters = shape == 0 ? 20000 : 40000;
+        const int iters = shape == 1 ? 40000 : shape == 0 ? 20000 : 10000;
         const size_t lds = (size_t)(160 / wps) * 1024;           // wps workgroups fit a CU
         const int blocks = cus * wps * 8;
-        const double flop_per_mfma = shape == 0 ? 32.0 * 32 * 16 * 2 : 16.0 * 16 * 32 * 2;
+        const double flop_per_mfma = shape != 1 ? 32.0 * 32 * 16 * 2 : 16.0 * 16 * 32 * 2;
         float ms = 0.f;
         for (int rep = 0; rep < 2; ++rep) {       // the second launch is the measurement
           CHECK(hipEventRecord(e0, 0));
           if (shape == 0) hipLaunchKernelGGL(spin<0>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
-          else hipLaunchKernelGGL(spin<1>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
+          else if (shape == 1) hipLaunchKernelGGL(spin<1>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
+          else hipLaunchKernelGGL(spin<2>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
           CHECK(hipEventRecord(e1, 0));
           CHECK(hipEventSynchronize(e1));
           CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -96,7 +122,7 @@ int main() {
         const double ghz = cyc / real * 0.1;
         const double tf = flop_per_mfma * iters * chains * n / (ms * 1e-3) / 1e12;
         printf("%s operands, %s, %d wave(s) per SIMD: %.1f cycles per MFMA seen by a wave = %.1f per SIMD, shader clock %.2f GHz, %.0f TFLOP/s\n",
-               random ? "random" : "zero", shape == 0 ? "32x32x16" : "16x16x32", wps, per_mfma_wave, per_mfma_wave / wps, ghz, tf);
+               random ? "random" : "zero", shape == 0 ? "32x32x16" : shape == 1 ? "16x16x32" : "32x32x16 (4 x 2 tiles)", wps, per_mfma_wave, per_mfma_wave / wps, ghz, tf);
       }
     }
   }
