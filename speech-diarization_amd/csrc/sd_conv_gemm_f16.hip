@@ -371,12 +371,13 @@ __device__ __forceinline__ void sd_direct_epilogue(const sd_conv_args& p, ACC (&
 //   swapped between the wave halves (-3 %), issuing the activation pieces later in the step (each later slot -2..-4 %),
 //   every wave's 8 pieces issued one at a time between groups of 8 MFMAs instead of as a block (-7 %: 1171 -> 1090).
 // * Where this kernel stands (tools/micro/mfma_rate.hip: register operands, no memory operation, random data, all CUs):
-//   v_mfma_f32_16x16x32_f16 sustains 1.30 PFLOP/s chip-wide (one MFMA per ~25 cycles and SIMD whatever the occupancy;
-//   1.49 on zeros at 2.39 GHz), v_mfma_f32_32x32x16_f16 1.72 (2.49 on zeros; the chip drops to 1.68 GHz on random data).
-//   1227 here is 95 % of the 16x16x32 figure.  The same ring / DMA schedule / read-ahead with 32x32x16 MFMAs (4 x 2
-//   tiles per wave, k-slices of 16, a register epilogue joined with v_permlane32_swap) measured 1036-1079 against
-//   1196-1212 in the same runs, as the round-1 structure had (1071 vs 1140): the higher ceiling of that instruction is
-//   not reached by this structure, and is the open question for the kernel.
+//   v_mfma_f32_32x32x16_f16 issues every 32 cycles but the chip drops to 1.6-1.7 GHz: 1.61-1.72 PFLOP/s (2.47 on zeros) is
+//   the power limit of the matrix pipe alone; v_mfma_f32_16x16x32_f16 issues at most every ~25 cycles per SIMD: 1.25-1.30 at
+//   2.0-2.1 GHz (1.48 on zeros).  This kernel's 1227 at 1.87 GHz, with its LDS reads, DMA and address arithmetic beside the
+//   MFMAs, is about three quarters of the pure-MFMA power roofline.  The same ring / DMA schedule / read-ahead with
+//   32x32x16 MFMAs (4 x 2 tiles per wave, k-slices of 16, register epilogue joined with v_permlane32_swap) measured
+//   1036-1079 against 1196-1212 in the same runs, as the round-1 structure had (1071 vs 1140): what is left is energy per
+//   flop outside the MFMA (LDS bytes and DMA pieces per flop), not schedule.
 // The 256x256 f32 C tile does not fit LDS: the epilogue runs once per 128-row half.
 // DIRECT: the MFMA operands are swapped (D = W . X^T: accumulator ROWS are output channels, its columns time rows),
 // so a lane holds 4 CONSECUTIVE channels of one output row per 16x16 tile and the epilogue runs from registers:
