@@ -4,7 +4,8 @@
 // 256-thread workgroups (one wave per SIMD), 1 / 2 / 4 of them resident per CU (limited by a dynamic LDS allocation),
 // 8 rounds of workgroups per CU; operands zero or random.  Reports cycles per MFMA seen by a wave (s_memtime), the shader
 // clock (s_memtime / s_memrealtime at 100 MHz) and chip TFLOP/s from HIP events.  The 2.5 PFLOP/s dense f16 figure
-// is 1024 flop per clock and SIMD at 2.4 GHz: one 32x32x16 MFMA per 32 cycles, one 16x16x32 per 16.
+// is 1024 flop per clock and SIMD at 2.4 GHz: one 32x32x16 MFMA per 32 cycles, one 16x16x32 per 16; the 157.3 TFLOP/s f32
+// figure is 64 flop per clock and SIMD: one 32x32x2 per 64 cycles, one 16x16x4 per 32.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +35,31 @@ __global__ __launch_bounds__(256) void spin(const h8* __restrict__ ops, int iter
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) out += acc[i][0] + acc[i][15];
+  } else if (SHAPE == 3 || SHAPE == 4) {   // exact f32: v_mfma_f32_32x32x2_f32 (4 chains) / v_mfma_f32_16x16x4_f32 (8 chains)
+    const float fa = (float)a[0], fb = (float)b[1];
+    if (SHAPE == 3) {
+      f32x16 acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out += acc[i][0] + acc[i][15];
+    } else {
+      f32x4 acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out += acc[i][0] + acc[i][3];
+    }
   } else if (SHAPE == 2) {
     f32x16 acc[4][2];
     h8 fa[4], fb[2];
@@ -88,6 +114,8 @@ int main() {
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spin<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spin<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spin<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spin<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spin<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
@@ -95,20 +123,22 @@ int main() {
   for (int random = 0; random < 2; ++random) {
     for (auto& v : host) v = (_Float16)(random ? (float)(rand() % 2001 - 1000) / 1000.f : 0.f);
     CHECK(hipMemcpy(ops, host.data(), host.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-    for (int shape = 0; shape < 3; ++shape) {
+    for (int shape = 0; shape < 5; ++shape) {
       for (int wps : {1, 2, 4}) {
         if (shape == 2 && wps == 4) continue;              // 140 registers: two waves per SIMD
-        const int chains = shape == 0 ? 4 : 8;
-        const int iters = shape == 1 ? 40000 : shape == 0 ? 20000 : 10000;
+        const int chains = shape == 0 || shape == 3 ? 4 : 8;
+        const int iters = shape == 1 ? 40000 : shape == 0 ? 20000 : shape == 2 ? 10000 : shape == 3 ? 10000 : 10000;
         const size_t lds = (size_t)(160 / wps) * 1024;           // wps workgroups fit a CU
         const int blocks = cus * wps * 8;
-        const double flop_per_mfma = shape != 1 ? 32.0 * 32 * 16 * 2 : 16.0 * 16 * 32 * 2;
+        const double flop_per_mfma = shape == 3 ? 32.0 * 32 * 2 * 2 : shape == 4 ? 16.0 * 16 * 4 * 2 : shape != 1 ? 32.0 * 32 * 16 * 2 : 16.0 * 16 * 32 * 2;
         float ms = 0.f;
         for (int rep = 0; rep < 2; ++rep) {       // the second launch is the measurement
           CHECK(hipEventRecord(e0, 0));
           if (shape == 0) hipLaunchKernelGGL(spin<0>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
           else if (shape == 1) hipLaunchKernelGGL(spin<1>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
-          else hipLaunchKernelGGL(spin<2>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
+          else if (shape == 2) hipLaunchKernelGGL(spin<2>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
+          else if (shape == 3) hipLaunchKernelGGL(spin<3>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
+          else hipLaunchKernelGGL(spin<4>, dim3(blocks), dim3(256), lds, 0, ops, iters, sink, stamps);
           CHECK(hipEventRecord(e1, 0));
           CHECK(hipEventSynchronize(e1));
           CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -122,7 +152,7 @@ int main() {
         const double ghz = cyc / real * 0.1;
         const double tf = flop_per_mfma * iters * chains * n / (ms * 1e-3) / 1e12;
         printf("%s operands, %s, %d wave(s) per SIMD: %.1f cycles per MFMA seen by a wave = %.1f per SIMD, shader clock %.2f GHz, %.0f TFLOP/s\n",
-               random ? "random" : "zero", shape == 0 ? "32x32x16" : shape == 1 ? "16x16x32" : "32x32x16 (4 x 2 tiles)", wps, per_mfma_wave, per_mfma_wave / wps, ghz, tf);
+               random ? "random" : "zero", shape == 0 ? "32x32x16 f16" : shape == 1 ? "16x16x32 f16" : shape == 2 ? "32x32x16 f16 (4 x 2 tiles)" : shape == 3 ? "32x32x2 f32" : "16x16x4 f32", wps, per_mfma_wave, per_mfma_wave / wps, ghz, tf);
       }
     }
   }
