@@ -153,6 +153,9 @@ int sd_conv1d_cl_f16(const sd_conv_args* args, sd_stream_t stream);
  * SD_TUNE_SKINNY_TILES: sd_conv1d_cl_f32 launches with fewer 128x128 tiles than `value` run the 32x32
  * split-K kernel (default 128; 0 = always the 128x128 kernel; negative = restore the default). */
 #define SD_TUNE_SKINNY_TILES 1
+/* SD_TUNE_WIDE_TILES: sd_conv1d_cl_f32 launches with cout >= 1024 and at least `value` 256x256 tiles run the 256x256 ring
+ * kernel (default 1024 = four rounds over the CUs; 0 = whenever the layer qualifies; negative = restore the default). */
+#define SD_TUNE_WIDE_TILES 2
 int sd_set_tuning(int key, long value);
 /* floats needed for sd_conv_args.colstat */
 size_t sd_colstat_floats(int M, int cout);

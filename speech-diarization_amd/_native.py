@@ -19,6 +19,7 @@ SD_LOG_LN_EPS, SD_LOG_DB_TOPDB = 0, 1
 SD_ACT_NONE, SD_ACT_RELU, SD_ACT_TANH, SD_ACT_SIGMOID = 0, 1, 2, 3
 SD_DT_F32, SD_DT_F16 = 0, 1
 SD_TUNE_SKINNY_TILES = 1
+SD_TUNE_WIDE_TILES = 2
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
 SD_ABI_VERSION = 5

@@ -368,6 +368,186 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
 
 
 // ------------------------------------------------------------------------------------------
+// 256x256 tile for the wide outputs (cout >= 1024: C -> C, 3C -> 3C) of large launches: the structure of the f16
+// kernel conv_gemm_f16_t256_kernel (sd_conv_gemm_f16.hip) with exact-f32 operands.  One workgroup of 8 waves per CU
+// (2 (M) x 4 (N), each 128 x 64 = 4 x 2 tiles of v_mfma_f32_32x32x2_f32, 128 accumulator registers); K step 32 floats =
+// 128-byte rows; the 160 KB of LDS hold THREE stages of A (activations, streamed from HBM) and TWO of B (weights), filled
+// by LDS-DMA: waves 0-3 fetch the weights of step k + 1, waves 4-7 the activations of step k + 2 (one step in flight
+// across the barrier, vmcnt(8)); a K step is four k-groups of 8 (6 fragment reads -> 32 MFMAs of 64 cycles), the reads
+// of group g + 1 sit in front of the MFMAs of group g and the barrier that opens step k + 1 in front of the LAST group's
+// MFMAs of step k, so a wave reaches every barrier with 2048 cycles of matrix work queued.
+// Why: exact-f32 MFMA is not power-limited (tools/micro/mfma_rate.hip: 155-156 TFLOP/s at 2.39 GHz on random data), and
+// the 128x128 kernel's K loop runs at 0.89 of that with its barrier + vmcnt(0) per step and two independent workgroups per
+// CU (a tile costs 0.1215 us per unit of K against 0.108 at the pipe's rate, plus 5.7 us).
+constexpr int WBM = 256, WBN = 256, WBK = 32;
+constexpr int W_ROW = 128;                            // bytes per staged row
+constexpr int W_A_STAGE = WBM * W_ROW;                // 32 KB
+constexpr int W_B_STAGE = WBN * W_ROW;
+constexpr int W_B_BASE = 3 * W_A_STAGE;
+constexpr int W_LDS_BYTES = W_B_BASE + 2 * W_B_STAGE;
+static_assert(W_LDS_BYTES == 160 * 1024, "ring fills the LDS exactly");
+static_assert((WBM / 2) * WBN * 4 <= W_LDS_BYTES, "half C tile must fit in the ring");
+
+__global__ __launch_bounds__(512, 2) void conv_gemm_f32_t256_kernel(const sd_conv_args p, const int vec) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+
+  const int n_tiles = (p.cout + WBN - 1) / WBN;
+  int wg;
+  {                                          // XCD-aware: workgroups b, b + 8, ... (one XCD) take consecutive tiles
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_n = wg % n_tiles;
+  const int tile_m = wg / n_tiles;
+  const int m0 = tile_m * WBM, n0 = tile_n * WBN;
+
+  // staging role: within its group of 256 threads, thread (r0 = lt / 8, ps = lt % 8) fills physical 16-byte slot ps of rows
+  // r0 + 32 i (i < 8) of ITS operand: waves 0-3 the weights, waves 4-7 the activations.  The slot holds logical k chunk
+  // ps ^ ((row >> 1) & 7), and (row >> 1) & 7 does not depend on i.
+  const bool bload = __builtin_amdgcn_readfirstlane(wid) < 4;
+  const int lt = tid & 255;
+  const int r0 = lt >> 3;
+  const int ls4 = ((lt & 7) ^ ((r0 >> 1) & 7)) * 4;
+  const int ktot = p.taps * p.cin_pad;
+  const int nk = p.taps * (p.cin_pad / WBK);
+  const int half = p.taps / 2;
+  const float* ptr[8];
+  const float* X = static_cast<const float*>(p.x) + p.a_col0;
+  auto set_tap = [&](int tap) {
+    const int delta = (tap - half) * p.dil;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int m = m0 + r0 + 32 * i;
+      m = m < p.M ? m : p.M - 1;
+      const int seg = (m / p.T) * p.T;
+      int tt = m - seg + delta;
+      tt = tt < 0 ? -tt : tt;
+      tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
+      ptr[i] = X + (size_t)(seg + tt) * p.lda;
+    }
+  };
+  if (bload) {
+    const float* W = static_cast<const float*>(p.w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int n = n0 + r0 + 32 * i;
+      n = n < p.cout ? n : p.cout - 1;
+      ptr[i] = W + (size_t)n * ktot + ls4;
+    }
+  } else {
+    set_tap(0);
+  }
+  int ld_tap = 0, ld_c0 = 0;
+  char* const dst = smem_raw + ((wid & 3) * 8) * W_ROW;
+  auto issue_b = [&](int st) {
+    char* base = dst + W_B_BASE + st * W_B_STAGE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      SD_GLDS16_F32(ptr[i], base + i * 32 * W_ROW);
+      ptr[i] += WBK;
+    }
+  };
+  auto issue_a = [&](int st) {
+    char* base = dst + st * W_A_STAGE;
+    const int col = ld_c0 + ls4;
+    const int acol = col < p.cin ? col : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) SD_GLDS16_F32(ptr[i] + acol, base + i * 32 * W_ROW);
+    ld_c0 += WBK;
+    if (ld_c0 >= p.cin_pad) {
+      ld_c0 = 0;
+      ++ld_tap;
+      if (ld_tap < p.taps) set_tap(ld_tap);
+    }
+  };
+
+  f32x16 acc[4][2];                          // [32-row tile][32-channel tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fn = lane & 31, fh = lane >> 5;
+  const int ab_sw = (fn >> 1) & 7;
+  const char* const a_base = smem_raw + (wm * 128 + fn) * W_ROW;
+  const char* const b_base = smem_raw + W_B_BASE + (wn * 64 + fn) * W_ROW;
+  // k-group g of a step (8 k): the lane reads 4 consecutive k at 8 g + 4 fh (logical chunk 2 g + fh) with one 16-byte
+  // access and feeds element r to MFMA r (same k permutation on both operands)
+  const int so0 = ((0 + fh) ^ ab_sw) << 4, so1 = ((2 + fh) ^ ab_sw) << 4, so2 = ((4 + fh) ^ ab_sw) << 4, so3 = ((6 + fh) ^ ab_sw) << 4;
+
+  f32x4 fa[2][4], fb[2][2];
+#define W3_READ(buf_, sa_, sb_, so_)                                                                             \
+  do {                                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+        fa[buf_][i] = *reinterpret_cast<const f32x4*>(a_base + (sa_) * W_A_STAGE + i * 32 * W_ROW + (so_));      \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+        fb[buf_][j] = *reinterpret_cast<const f32x4*>(b_base + (sb_) * W_B_STAGE + j * 32 * W_ROW + (so_));      \
+  } while (0)
+#define W3_MMA(buf_)                                                                                             \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf_][i][r], fb[buf_][j][r], acc[i][j], 0, 0, 0)
+
+  if (bload) {
+    issue_b(0);
+  } else {
+    issue_a(0);
+    if (nk > 1) issue_a(1);
+  }
+  int sa = 0, sb = 0;                        // stages of step kt
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- barrier(kt): this step's stages have landed, every wave has finished reading the previous step's
+    if (bload || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");      // the activations of step kt + 1 stay in flight
+    __builtin_amdgcn_s_barrier();
+    const int sa2 = sa == 0 ? 2 : sa - 1;                                  // (sa + 2) % 3 = the A stage of step kt - 1
+    W3_READ(0, sa, sb, so0);
+    if (kt > 0) { W3_MMA(1); }                                             // deferred group 3 of step kt - 1
+    if (bload && kt + 1 < nk) issue_b(sb ^ 1);
+    W3_READ(1, sa, sb, so1);
+    W3_MMA(0);
+    if (!bload && kt + 2 < nk) issue_a(sa2);
+    W3_READ(0, sa, sb, so2);
+    W3_MMA(1);
+    W3_READ(1, sa, sb, so3);
+    W3_MMA(0);                                                             // (group 3 runs behind the next barrier)
+    sa = sa == 2 ? 0 : sa + 1;
+    sb ^= 1;
+  }
+  W3_MMA(1);
+#undef W3_READ
+#undef W3_MMA
+
+  // ---- epilogue through LDS, one 128-row half at a time (the 256 x 256 f32 C tile does not fit)
+  __syncthreads();
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+  for (int hm = 0; hm < 2; ++hm) {
+    if (wm == hm) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cl = wn * 64 + j * 32 + fn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Cs[(i * 32 + 8 * (e >> 2) + 4 * fh + (e & 3)) * WBN + cl] = acc[i][j][e];
+        }
+      }
+    }
+    __syncthreads();
+    sd_store_tile<float, WBM / 2, WBN, 512, 1, 2>(p, Cs, WBN, m0 + hm * (WBM / 2), n0, tid, vec);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Launches with fewer 128x128 tiles than the chip has CUs: the per-segment layers (SE squeeze/excite,
 // global-context bias, final FC: M = B rows) and, at the reference's own batch sizes (16-128
 // segments), the narrow Res2Net convs (51 tiles at 32 segments: a 100 k-cycle tile on a fifth of the
@@ -461,9 +641,15 @@ std::atomic<long> g_skinny_below{[] {
 }()};
 }  // namespace
 
+namespace { std::atomic<long> g_wide_from{1024L}; }
+
 extern "C" int sd_set_tuning(int key, long value) {
   if (key == SD_TUNE_SKINNY_TILES) {
     g_skinny_below.store(value < 0 ? 128L : value, std::memory_order_relaxed);
+    return SD_OK;
+  }
+  if (key == SD_TUNE_WIDE_TILES) {
+    g_wide_from.store(value < 0 ? 1024L : value, std::memory_order_relaxed);
     return SD_OK;
   }
   return sd_set_error(SD_ERR_ARG, "sd_set_tuning: unknown key %d", key);
@@ -527,6 +713,22 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
     hipLaunchKernelGGL(skinny_gemm_f32_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
     SD_CHECK_LAUNCH("skinny_gemm_f32_kernel");
     return SD_OK;
+  }
+  // wide outputs of large launches: the 256x256 ring kernel (SD_F32_WIDE=0: A/B switch; no tee_add epilogue, column
+  // statistics only for tiles that span <= 2 segments, at least four rounds of tiles over the CUs)
+  static const bool wide_ok = [] { const char* e = getenv("SD_F32_WIDE"); return !(e && e[0] == '0'); }();
+  {
+    const long t256 = ((a->M + WBM - 1) / WBM) * ((a->cout + WBN - 1) / WBN);
+    if (wide_ok && !symmetric && a->cout >= 1024 && t256 >= g_wide_from.load(std::memory_order_relaxed) && t256 > 0 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128)) {
+      SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_t256_kernel), W_LDS_BYTES));
+      {
+        SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream),
+                         2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
+        hipLaunchKernelGGL(conv_gemm_f32_t256_kernel, dim3((unsigned)t256), dim3(512), W_LDS_BYTES, static_cast<hipStream_t>(stream), *a, vec);
+      }
+      SD_CHECK_LAUNCH("conv_gemm_f32_t256_kernel");
+      return SD_OK;
+    }
   }
   // SD_F32_DMA=0|1 (diagnostic): operand staging through registers or by LDS-DMA
   static const int dma = [] {

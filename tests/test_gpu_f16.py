@@ -123,6 +123,19 @@ def test_fused_attention_pooling_matches_f64(dev, B, T, Cc, dtype):
     assert (got[:, :Cc] - two[:, :Cc].cpu().double()).abs().max() < (2e-2 if dtype == torch.float16 else 2e-5)
 
 
+@pytest.mark.parametrize("B,T,cin,cout", [(3, 150, 64, 1024), (7, 301, 128, 1024), (5, 201, 96, 2048)])
+def test_wide_f32_kernel_column_statistics(dev, B, T, cin, cout):
+    """The 256x256 f32 ring kernel (large launches of the wide layers) behind the same statistics contract; pinned here by the
+    tuning knob because test-sized launches would never select it."""
+    from speech_diarization_amd import _native as N
+    lib = N.load()
+    N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, 0), "sd_set_tuning")
+    try:
+        test_epilogue_column_statistics(dev, torch.float32, B, T, cin, cout)
+    finally:
+        N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, -1), "sd_set_tuning")
+
+
 def test_fused_attention_pooling_refuses_what_it_does_not_cover(dev):
     from speech_diarization_amd import ops
     assert not ops.asp_attend_pool_supported(torch.float16, 300, 256, 128)

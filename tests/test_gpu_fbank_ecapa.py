@@ -114,14 +114,16 @@ def test_fbank_short_segments_and_errors(dev):
         fbank_device(torch.zeros(1600, device=dev), plan)
 
 
-@pytest.fixture(params=["auto", "tiles128"])
+@pytest.fixture(params=["auto", "tiles128", "wide256"])
 def conv_kernel(request):
     """"tiles128" pins the 128x128 f32 conv kernel; "auto" lets small launches take the 32x32 split-K kernel."""
     from speech_diarization_amd import _native as N
     lib = N.load()
-    N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, 0 if request.param == "tiles128" else -1), "sd_set_tuning")
+    N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, 0 if request.param != "auto" else -1), "sd_set_tuning")
+    N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, 0 if request.param == "wide256" else -1), "sd_set_tuning")   # cout >= 1024 layers: the 256x256 ring kernel
     yield request.param
     N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, -1), "sd_set_tuning")
+    N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, -1), "sd_set_tuning")
 
 
 @pytest.mark.parametrize("width,B,n", [(64, 6, 16000), (128, 3, 32000)])
