@@ -12,7 +12,8 @@ HIP fbank -> HIP ECAPA-TDNN forward (spkrec-ecapa geometry, 20.8 M random-init p
 block on-device.  Weak scaling: every rank owns `--segments` segments.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the implicit-GEMM
-conv on the f32 matrix cores); `roofline_fbank` is the HBM-bound fbank kernel.  Kernel
+conv of the wide layers on the f32 matrix cores); `roofline_other_convs` the remaining conv launches;
+`roofline_fbank` is the HBM-bound fbank kernel.  Kernel
 durations are measured live with HIP events on the launch stream (sd_profile_*).
 `cpu_baseline` times the CPU oracle (torch f32) on this host's cores on a bounded sample.
 """
@@ -167,6 +168,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         conv = _native.profile_read(_native.SD_PROF_CONV_GEMM)
+        wide = _native.profile_read(_native.SD_PROF_CONV_WIDE)
         fb = _native.profile_read(_native.SD_PROF_FBANK)
         _native.profile_enable(False)
         if world > 1:
@@ -175,16 +177,16 @@ def main():
             dt = float(t.item())
         if not bool(torch.isfinite(emb).all()):
             raise SystemExit("non-finite embeddings")
-        return dt, conv, fb, emb
+        return dt, conv, fb, emb, wide
 
-    dt, (conv_ms, conv_n, conv_flops), (fb_ms, fb_n, fb_bytes), emb = measure(engine)
+    dt, (conv_ms, conv_n, conv_flops), (fb_ms, fb_n, fb_bytes), emb, (wide_ms, wide_n, wide_flops) = measure(engine)
     extra_f16 = None
     if args.precision == "f32" and not args.no_f16_extra:
         emb32 = emb.clone()
         del engine
         torch.cuda.empty_cache()
         eng16 = EmbeddingEngine(state_dict, dev, max_batch=args.micro_batch, precision="f16")
-        dt16, (c16_ms, c16_n, c16_flops), _, emb16 = measure(eng16)
+        dt16, (n16_ms, n16_n, n16_flops), _, emb16, (c16_ms, c16_n, c16_flops) = measure(eng16)
         cosd = 1.0 - torch.nn.functional.cosine_similarity(emb16.double(), emb32.double(), dim=1)
         c16_tf = c16_flops / (c16_ms * 1e-3) / 1e12 if c16_ms > 0 else 0.0
         extra_f16 = {
@@ -193,9 +195,11 @@ def main():
                     "CUDA matmuls/convs [REF diarization_baseline.py:20-21]; NOT the headline value",
             "value": n_total * args.steps / dt16, "unit": "segments/s", "ms_per_step": dt16 / args.steps * 1e3, "dtype": "f16",
             "max_cosine_distance_vs_f32_path": float(cosd.max().item()),
-            "roofline": {"kernel": "conv_gemm_f16_kernel", "bound": "mfma", "achieved": c16_tf, "peak": F16_MFMA_PEAK_TFLOPS,
+            "roofline": {"kernel": "conv_gemm_f16_t256_kernel", "bound": "mfma", "achieved": c16_tf, "peak": F16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": c16_tf / F16_MFMA_PEAK_TFLOPS, "launches": c16_n,
                          "avg_launch_ms": c16_ms / max(c16_n, 1), "share_of_step_time": c16_ms * 1e-3 / dt16,
+                         "other_conv_kernels": {"kernels": "res2net_chain_f16_kernel, conv_gemm_f16_kernel, skinny/f32 per-segment layers", "launches": n16_n,
+                                                "achieved": n16_flops / (n16_ms * 1e-3) / 1e12 if n16_ms > 0 else 0.0, "share_of_step_time": n16_ms * 1e-3 / dt16},
                          "mfma_util_pmc": {k: (v or {}).get("mfma_util") for k, v in load_profile_json("mfma_util_f16.json").items()
                                            if k.startswith("conv_gemm_f16")},
                          "mfma_util_pmc_source": "file profiles/mfma_util_f16.json (separate rocprofv3 --pmc pass of `bench.py --precision f16`); NOT measured in this run"},
@@ -204,10 +208,17 @@ def main():
     if rank == 0:
         traffic = load_traffic()
         value = n_total * args.steps / dt
+        # dominant kernel: the 256x256 ring kernel of the wide layers (90 % of the step's flops); the other conv launches
+        # (Res2Net convs / chain, stem at f32, attention TDNN, affinity) are reported beside it
+        narrow_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        narrow_ms, narrow_n = conv_ms, conv_n
+        if wide_n > 0:
+            conv_ms, conv_n, conv_flops = wide_ms, wide_n, wide_flops
         conv_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         half = args.precision == "f16"
         mfma_peak = F16_MFMA_PEAK_TFLOPS if half else F32_MFMA_PEAK_TFLOPS
-        conv_kernel = "conv_gemm_f16_kernel" if half else "conv_gemm_f32_kernel"
+        other_kernel = "conv_gemm_f16_kernel" if half else "conv_gemm_f32_kernel"
+        conv_kernel = ("conv_gemm_f16_t256_kernel" if half else "conv_gemm_f32_t256_kernel") if wide_n > 0 else other_kernel   # (launches too small for the wide kernel)
         fb_gbs = fb_bytes / (fb_ms * 1e-3) / 1e9 if fb_ms > 0 else 0.0
         out = {
             "metric": "segment-embeddings/sec (2 s @16 kHz)",
@@ -244,6 +255,12 @@ def main():
                 "launches": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
                 "flops_per_launch": conv_flops / max(conv_n, 1),
                 "share_of_step_time": conv_ms * 1e-3 / dt,
+            },
+            "roofline_other_convs": {
+                "kernel": other_kernel + (" (+ res2net_chain_f16_kernel)" if half else ""), "bound": "mfma", "achieved": narrow_tflops,
+                "peak": mfma_peak, "unit": "TFLOP/s", "frac": narrow_tflops / mfma_peak, "launches": narrow_n,
+                "avg_launch_ms": narrow_ms / max(narrow_n, 1), "share_of_step_time": narrow_ms * 1e-3 / dt,
+                "traffic": traffic.get(other_kernel), "traffic_source": "file profiles/traffic.json; NOT measured in this run",
             },
             "roofline_fbank": {
                 "kernel": "fbank_logmel_kernel", "bound": "hbm",

@@ -62,10 +62,11 @@ int sd_device_count(void);
  * roofline figures.  While enabled every launch of the named kernel families is
  * bracketed by two events; sd_profile_read synchronises them and returns the summed
  * duration, the launch count and the summed algorithmic work (flops for
- * SD_PROF_CONV_GEMM, bytes for SD_PROF_FBANK) since the last sd_profile_enable(1). */
+ * SD_PROF_CONV_GEMM / SD_PROF_CONV_WIDE, bytes for SD_PROF_FBANK) since the last sd_profile_enable(1). */
 #define SD_PROF_CONV_GEMM 0
 #define SD_PROF_FBANK 1
-#define SD_PROF_KINDS 2
+#define SD_PROF_CONV_WIDE 2   /* the 256x256 ring kernels of the wide layers (cout >= 1024), f32 and f16 */
+#define SD_PROF_KINDS 3
 int sd_profile_enable(int on);
 int sd_profile_read(int kind, double* ms, long long* launches, double* work);
 

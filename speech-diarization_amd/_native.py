@@ -23,7 +23,7 @@ SD_TUNE_WIDE_TILES = 2
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
 SD_ABI_VERSION = 5
-SD_PROF_CONV_GEMM, SD_PROF_FBANK = 0, 1
+SD_PROF_CONV_GEMM, SD_PROF_FBANK, SD_PROF_CONV_WIDE = 0, 1, 2
 
 
 def profile_enable(on: bool) -> None:

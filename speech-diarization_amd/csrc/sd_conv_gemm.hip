@@ -722,7 +722,7 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
     if (wide_ok && !symmetric && a->cout >= 1024 && t256 >= g_wide_from.load(std::memory_order_relaxed) && t256 > 0 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128)) {
       SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_t256_kernel), W_LDS_BYTES));
       {
-        SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream),
+        SdProfScope prof(SD_PROF_CONV_WIDE, static_cast<hipStream_t>(stream),
                          2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
         hipLaunchKernelGGL(conv_gemm_f32_t256_kernel, dim3((unsigned)t256), dim3(512), W_LDS_BYTES, static_cast<hipStream_t>(stream), *a, vec);
       }

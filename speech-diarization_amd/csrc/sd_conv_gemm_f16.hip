@@ -582,7 +582,7 @@ int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
   auto kern = conv_gemm_f16_t256_kernel<TO, DIRECT>;
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), R3_LDS_BYTES));
   {
-    SdProfScope prof(SD_PROF_CONV_GEMM, stream, 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
+    SdProfScope prof(SD_PROF_CONV_WIDE, stream, 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), R3_LDS_BYTES, stream, *a, vec);
   }
   SD_CHECK_LAUNCH("conv_gemm_f16_t256_kernel");
