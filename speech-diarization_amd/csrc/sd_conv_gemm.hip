@@ -379,6 +379,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
 // Why: exact-f32 MFMA is not power-limited (tools/micro/mfma_rate.hip: 155-156 TFLOP/s at 2.39 GHz on random data), and
 // the 128x128 kernel's K loop runs at 0.89 of that with its barrier + vmcnt(0) per step and two independent workgroups per
 // CU (a tile costs 0.1215 us per unit of K against 0.108 at the pipe's rate, plus 5.7 us).
+// Measured and not kept: a register epilogue as in the f16 kernel (operands swapped, 16-byte stores of 4 channels per lane,
+// column statistics by DPP + one cross-row shuffle): 138.1 against 139.4 TFLOP/s on 1024 x 1024 — its stores cover 32
+// bytes per row and instruction where the LDS-staged epilogue writes whole rows.
 constexpr int WBM = 256, WBN = 256, WBK = 32;
 constexpr int W_ROW = 128;                            // bytes per staged row
 constexpr int W_A_STAGE = WBM * W_ROW;                // 32 KB
