@@ -10,11 +10,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128); ap.add_argument("--n", type=int, default=32000)
 ap.add_argument("--reps", type=int, default=50); ap.add_argument("--precision", default="f32")
 ap.add_argument("--skinny", type=int, default=-1, help="SD_TUNE_SKINNY_TILES override")
+ap.add_argument("--wide", type=int, default=-1, help="SD_TUNE_WIDE_TILES override (256x256 tiles from which the f32 ring kernel takes the wide layers)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 if a.skinny >= 0:
     from speech_diarization_amd import _native
     _native.check(_native.load().sd_set_tuning(_native.SD_TUNE_SKINNY_TILES, a.skinny), "sd_set_tuning")
+if a.wide >= 0:
+    from speech_diarization_amd import _native
+    _native.check(_native.load().sd_set_tuning(_native.SD_TUNE_WIDE_TILES, a.wide), "sd_set_tuning")
 eng = EmbeddingEngine(synth.make_ecapa_state_dict(1234), dev, max_batch=max(a.batch, 16), precision=a.precision)
 x = torch.from_numpy(synth.synthetic_segments(5, a.batch, a.n)).to(dev)
 for _ in range(20): eng.embed(x)
