@@ -374,10 +374,12 @@ __device__ __forceinline__ void sd_direct_epilogue(const sd_conv_args& p, ACC (&
 //   v_mfma_f32_32x32x16_f16 issues every 32 cycles but the chip drops to 1.6-1.7 GHz: 1.61-1.72 PFLOP/s (2.47 on zeros) is
 //   the power limit of the matrix pipe alone; v_mfma_f32_16x16x32_f16 issues at most every ~25 cycles per SIMD: 1.25-1.30 at
 //   2.0-2.1 GHz (1.48 on zeros).  This kernel's 1227 at 1.87 GHz, with its LDS reads, DMA and address arithmetic beside the
-//   MFMAs, is about three quarters of the pure-MFMA power roofline.  The same ring / DMA schedule / read-ahead with
-//   32x32x16 MFMAs (4 x 2 tiles per wave, k-slices of 16, register epilogue joined with v_permlane32_swap) measured
-//   1036-1079 against 1196-1212 in the same runs, as the round-1 structure had (1071 vs 1140): what is left is energy per
-//   flop outside the MFMA (LDS bytes and DMA pieces per flop), not schedule.
+//   MFMAs, is 25.6 cycles per MFMA and SIMD: the pipe is saturated at this instruction's rate and the clock is what the
+//   power limit allows.  The same ring / DMA schedule / read-ahead with 32x32x16 MFMAs (4 x 2 tiles per wave, k-slices of
+//   16, register epilogue joined with v_permlane32_swap) measured 1036-1079 against 1196-1212 in the same runs, as the
+//   round-1 structure had (1071 vs 1140): its pipe is ~59 % busy — a K step's 64 KB through the 64 B/clk LDS-DMA path is
+//   half of a saturated step, plus the fragment reads and the barrier: that instruction needs fewer operand bytes per flop
+//   than this tile shape moves.
 // The 256x256 f32 C tile does not fit LDS: the epilogue runs once per 128-row half.
 // DIRECT: the MFMA operands are swapped (D = W . X^T: accumulator ROWS are output channels, its columns time rows),
 // so a lane holds 4 CONSECUTIVE channels of one output row per 16x16 tile and the epilogue runs from registers:
