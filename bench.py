@@ -198,6 +198,8 @@ def main():
             "roofline": {"kernel": "conv_gemm_f16_t256_kernel", "bound": "mfma", "achieved": c16_tf, "peak": F16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": c16_tf / F16_MFMA_PEAK_TFLOPS, "launches": c16_n,
                          "avg_launch_ms": c16_ms / max(c16_n, 1), "share_of_step_time": c16_ms * 1e-3 / dt16,
+                         "traffic": load_profile_json("traffic_f16.json").get("conv_gemm_f16_t256_kernel"),
+                         "traffic_source": "file profiles/traffic_f16.json (separate rocprofv3 --pmc passes of `bench.py --precision f16`); NOT measured in this run",
                          "other_conv_kernels": {"kernels": "res2net_chain_f16_kernel, conv_gemm_f16_kernel, skinny/f32 per-segment layers", "launches": n16_n,
                                                 "achieved": n16_flops / (n16_ms * 1e-3) / 1e12 if n16_ms > 0 else 0.0, "share_of_step_time": n16_ms * 1e-3 / dt16},
                          "mfma_util_pmc": {k: (v or {}).get("mfma_util") for k, v in load_profile_json("mfma_util_f16.json").items()

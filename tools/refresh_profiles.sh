@@ -12,5 +12,8 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_
   timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$tag -- python3 bench.py --steps 1 --warmup 0 --no-f16-extra --no-cpu-baseline > $out/pmc_$tag.log 2>&1
 done
 
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${c}_f16 -- python3 bench.py --precision f16 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_${c}_f16.log 2>&1
+done
 timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma_f16 -- python3 bench.py --precision f16 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_mfma_f16.log 2>&1
 find $out -name "*.csv" | sort
