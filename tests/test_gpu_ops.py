@@ -43,6 +43,9 @@ def conv_kernel(request):
     (2, 201, 80, 256, 5, 1),        # stem: cin not a multiple of the K step
     (7, 1, 1024, 128, 1, 1),        # SE squeeze: T = 1, tiny M
     (4, 33, 256, 192, 1, 1),        # cout not a multiple of the N tile
+    (2, 150, 96, 1280, 3, 2),       # wide output, 5 column tiles of 256, dilated taps, M = 300 (second row tile almost empty)
+    (1, 300, 64, 1100, 1, 1),       # wide output that cannot take 16-byte stores (cout % 8 != 0): scalar epilogue
+    (3, 201, 80, 1024, 5, 1),       # the stem at full width: cin not a multiple of the K step, five taps
 ])
 def test_conv1d_cl_matches_torch(dev, conv_kernel, B, T, cin, cout, k, dil):
     from speech_diarization_amd import ops
