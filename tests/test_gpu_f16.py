@@ -301,7 +301,8 @@ def _chain_f64(r, layers, T):
 
 
 @pytest.mark.parametrize("B,T,dil,n", [(5, 201, 2, 7), (3, 201, 3, 7), (4, 201, 4, 7), (6, 101, 2, 7), (2, 61, 3, 7), (3, 212, 4, 7),
-                                       (2, 16, 2, 7), (1, 5, 4, 3), (2, 208, 2, 1)])
+                                       (2, 16, 2, 7), (1, 5, 4, 3), (2, 208, 2, 1),
+                                       (2, 96, 2, 7), (2, 150, 3, 7), (2, 170, 2, 5), (2, 33, 2, 7), (1, 64, 3, 7), (1, 32, 2, 2)])   # every count of 32-row tiles, tile-aligned and one row over
 def test_res2net_chain_matches_f64_and_the_unfused_convs(dev, B, T, dil, n):
     from speech_diarization_amd import ops
     assert ops.res2net_chain_supported(T, 128, n, 3, dil)
