@@ -70,7 +70,7 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(state_dict, wav_dev, budget_s):
+def cpu_baseline(state_dict, wav_dev, budget_s, emb_gpu=None, emb_gpu_f16=None):
     """The CPU oracle (torch f32: torch.stft fbank + F.conv1d ECAPA) on the host cores, as SURVEY.md §8(d) /
     BASELINE.md §3 prescribe: batches of 32 (the reference's embed_segments batch, [REF anti_stick_diarize.py:134])
     and of 128 (its reassignment batch, [REF :398]), 20 warm-up segments, >= 200 timed segments per batch size
@@ -91,6 +91,15 @@ def cpu_baseline(state_dict, wav_dev, budget_s):
         rates[batch] = (done, time.perf_counter() - t0)
     d32, t32 = rates[32]
     d128, t128 = rates[128]
+    # BASELINE.md §3 / SURVEY §8(d): max 1 - cos(e_gpu, e_cpu) over the first 64 bench segments (north_star bar: 1e-3)
+    parity = {}
+    if emb_gpu is not None:
+        e_cpu = encode_batch_ref(state_dict, sample[:64], torch.float32, net).astype(np.float64)
+        for key, e in (("max_cosine_distance_vs_gpu", emb_gpu), ("max_cosine_distance_vs_gpu_f16", emb_gpu_f16)):
+            if e is not None:
+                g = e[:64].double().cpu().numpy()
+                parity[key] = float((1.0 - (g * e_cpu).sum(1) / (np.linalg.norm(g, axis=1) * np.linalg.norm(e_cpu, axis=1))).max())
+        parity["parity_segments"] = 64
     try:
         model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
     except (OSError, IndexError):
@@ -98,7 +107,7 @@ def cpu_baseline(state_dict, wav_dev, budget_s):
     return {"value": d32 / t32, "unit": "segments/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{d32} of the same synthetic 2 s segments at batch 32 in {t32:.1f} s ({d32 / t32:.1f}/s) and {d128} at batch 128 in "
                       f"{t128:.1f} s ({d128 / t128:.1f}/s), after 20 warm-up segments; torch-CPU f32 oracle on {model}",
-            "batch32": d32 / t32, "batch128": d128 / t128, "cpu_model": model}
+            "batch32": d32 / t32, "batch128": d128 / t128, "cpu_model": model, **parity}
 
 
 def load_profile_json(name):
@@ -151,12 +160,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    aff_ms = [0.0]          # average duration of one affinity call (l2norm + tiled product) of the last measure()
+
     def measure(eng):
         """W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
-        def step():
+        aff_events = []
+
+        def step(timed=False):
             emb = eng.embed(wav)
             full = sdist.all_gather_embeddings(emb, n_total)
+            if timed:       # the affinity runs on torch's current stream: events on that stream bracket its launches
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             ops.cosine_affinity(full, out=aff, rows=(lo, hi))
+            if timed:
+                e1.record()
+                aff_events.append((e0, e1))
             return emb
         for _ in range(args.warmup):
             step()
@@ -164,9 +183,10 @@ def main():
         _native.profile_enable(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            emb = step()
+            emb = step(True)
         fence()
         dt = time.perf_counter() - t0
+        aff_ms[0] = sum(a.elapsed_time(b) for a, b in aff_events) / max(len(aff_events), 1)
         conv = _native.profile_read(_native.SD_PROF_CONV_GEMM)
         wide = _native.profile_read(_native.SD_PROF_CONV_WIDE)
         fb = _native.profile_read(_native.SD_PROF_FBANK)
@@ -180,7 +200,9 @@ def main():
         return dt, conv, fb, emb, wide
 
     dt, (conv_ms, conv_n, conv_flops), (fb_ms, fb_n, fb_bytes), emb, (wide_ms, wide_n, wide_flops) = measure(engine)
+    affinity_ms = aff_ms[0]
     extra_f16 = None
+    emb16 = None
     if args.precision == "f32" and not args.no_f16_extra:
         emb32 = emb.clone()
         del engine
@@ -274,10 +296,28 @@ def main():
                 "share_of_step_time": fb_ms * 1e-3 / dt,
             },
         }
+        # cosine affinity of this rank's row block ("report both fractions"): algorithmic bytes
+        # 4 rows N (the block written once) + 768 N (the embeddings read once), flops 384 rows N
+        a_rows = hi - lo
+        a_bytes = 4.0 * a_rows * n_total + 768.0 * n_total
+        a_flops = 384.0 * a_rows * n_total
+        if affinity_ms > 0:
+            out["roofline_affinity"] = {
+                "kernel": "l2norm_rows_kernel + conv_gemm_f32_kernel (x == w: upper triangle + mirror when the block is the full matrix)",
+                "rows": a_rows, "cols": n_total, "avg_call_ms": affinity_ms, "share_of_step_time": affinity_ms * 1e-3 * args.steps / dt,
+                "bytes": {"bound": "hbm", "achieved": a_bytes / (affinity_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": a_bytes / (affinity_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": a_bytes},
+                "flops": {"bound": "mfma", "achieved": a_flops / (affinity_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": a_flops / (affinity_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops": a_flops,
+                          "note": "algorithmic-equivalent: the full-matrix flops; the symmetric path computes the upper triangle only"},
+                "timing": "torch.cuda.Event pairs on the launch stream around every timed call",
+            }
         if extra_f16 is not None:
             out["f16"] = extra_f16
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(state_dict, wav, args.cpu_seconds)
+            e32 = emb if args.precision == "f32" else None
+            out["cpu_baseline"] = cpu_baseline(state_dict, wav, args.cpu_seconds, e32 if extra_f16 is None else emb32,
+                                               emb16 if extra_f16 is not None else (emb if args.precision == "f16" else None))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

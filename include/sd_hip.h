@@ -51,7 +51,7 @@ typedef void* sd_stream_t; /* hipStream_t */
 #define SD_ERR_WORKSPACE (-3)
 #define SD_ERR_HIP (-4)
 
-#define SD_ABI_VERSION 5
+#define SD_ABI_VERSION 6
 
 int sd_abi_version(void);
 const char* sd_last_error(void);
@@ -97,10 +97,23 @@ size_t sd_fbank_workspace_bytes(const sd_fbank_plan* plan, int B, int n);
 
 /* wav_dev: device f32 [B][n]; out_dev: device f32 [B][T][n_mels]
  * (ld_out = row stride of out in floats, >= n_mels);
- * mean_norm != 0 subtracts each utterance's per-bin mean over T. */
+ * mean_norm != 0 subtracts each utterance's per-bin mean over T.
+ * Input domain: samples with |x| <= 16 are processed exactly (audio is normalised to [-1, 1] everywhere on this
+ * path); larger magnitudes are clipped to +-16 (the split-f16 DFT scales the folded sums by 2^10 and they must
+ * stay inside the f16 range), so any finite input gives finite features; a NaN sample gives NaN features. */
 int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int B, int n,
                  int mean_norm, float* out_dev, int ld_out,
                  void* ws_dev, size_t ws_bytes, sd_stream_t stream);
+
+/* The same transform over B windows of ONE signal (the reference's callers embed overlapping windows of one
+ * recording: SCD windows [REF anti_stick_diarize.py:82-100], reassignment windows [REF anti_stick_diarize.py:396-430]):
+ * row b is wav_dev[starts_dev[b] .. starts_dev[b] + n), with zeros wherever that index falls outside [0, n_total)
+ * (the reference zero-pads short tails, [REF anti_stick_diarize.py:163-168]).  Bitwise the result of sd_fbank_f32 on
+ * the gathered [B][n] matrix, without materialising it: the signal is uploaded once, not once per overlapping window.
+ * wav_dev: device f32 [n_total]; starts_dev: device int64 [B]. */
+int sd_fbank_windows_f32(const sd_fbank_plan* plan, const float* wav_dev, long long n_total, const long long* starts_dev,
+                         int B, int n, int mean_norm, float* out_dev, int ld_out,
+                         void* ws_dev, size_t ws_bytes, sd_stream_t stream);
 
 /* --------------------------------------------------------- layer operators */
 

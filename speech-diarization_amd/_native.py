@@ -22,7 +22,7 @@ SD_TUNE_SKINNY_TILES = 1
 SD_TUNE_WIDE_TILES = 2
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
-SD_ABI_VERSION = 5
+SD_ABI_VERSION = 6
 SD_PROF_CONV_GEMM, SD_PROF_FBANK, SD_PROF_CONV_WIDE = 0, 1, 2
 
 
@@ -104,6 +104,7 @@ PROTOTYPES = {
     "sd_fbank_num_frames": (_I, [_P, _I]),
     "sd_fbank_workspace_bytes": (_Z, [_P, _I, _I]),
     "sd_fbank_f32": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    "sd_fbank_windows_f32": (_I, [_P, _P, C.c_longlong, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_conv1d_cl_f32": (_I, [C.POINTER(sd_conv_args), _P]),
     "sd_conv1d_cl_f16": (_I, [C.POINTER(sd_conv_args), _P]),
     "sd_set_tuning": (_I, [_I, C.c_long]),
@@ -152,7 +153,7 @@ def load() -> C.CDLL:
             return _lib
         import os
         lib_path = LIB_PATH
-        if os.environ.get("SD_HIP_LIB"):          # A/B experiment builds (build_native.py --variant); never set in product runs
+        if os.environ.get("SD_HIP_LIB") and os.environ.get("SD_EXPERIMENT") == "1":   # A/B builds (build_native.py --variant); never in product runs
             lib_path = Path(os.environ["SD_HIP_LIB"])
             if not lib_path.exists():
                 raise RuntimeError(f"SD_HIP_LIB={lib_path} does not exist")

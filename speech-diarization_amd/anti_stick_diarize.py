@@ -85,17 +85,26 @@ def scd_split_segments(y: np.ndarray, sr: int, segments: list[Segment], win_ms: 
     min_speech_s = min_speech_ms / 1000.0
 
     # pass 1: window every segment; all windows share one length, so they embed in common batches
-    views, counts = [], []
+    views, counts, starts = [], [], []
+    win = int(round(win_ms / 1000.0 * sr))
+    hop = int(round(hop_ms / 1000.0 * sr))
     for seg in segments:
-        sub = y[int(seg.start * sr): int(seg.end * sr)]
-        win = int(round(win_ms / 1000.0 * sr))
+        a = int(seg.start * sr)
+        sub = y[a: int(seg.end * sr)]
         snips = frame_audio(sub, sr, win_ms=win_ms, hop_ms=hop_ms) if sub.shape[0] >= win else np.empty((0, win), np.float32)
         if len(snips) < 3:
             counts.append(0)
             continue
         views.append(snips)
         counts.append(len(snips))
-    embs_all = _encode_rows(np.concatenate(views, axis=0), encode, rows_per_call) if views else None
+        starts.append(a + hop * np.arange(len(snips), dtype=np.int64))      # where frame_audio's rows sit in y
+    if not views:
+        embs_all = None
+    elif use_gpu:       # the signal goes up once and the windows are read in place (no 5x overlapping host gather)
+        from .speech_encode import using_ecapa_encoder
+        embs_all = using_ecapa_encoder().encode_windows(y, np.concatenate(starts), win, rows_per_call=rows_per_call)
+    else:
+        embs_all = _encode_rows(np.concatenate(views, axis=0), encode, rows_per_call)
 
     # pass 2: per-segment change detection
     out: list[Segment] = []
@@ -278,12 +287,10 @@ def _assign_windows_gpu(y: np.ndarray, starts: np.ndarray, win_samples: int, c_m
     yd = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)).to(dev)
     cd = torch.from_numpy(np.ascontiguousarray(c_matrix, dtype=np.float32)).to(dev)
     sd = torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int64)).to(dev)
-    ar = torch.arange(win_samples, device=dev)
     best = []
     with torch.inference_mode():
         for lo in range(0, sd.numel(), rows_per_call):
-            wav = yd[sd[lo: lo + rows_per_call, None] + ar[None, :]]
-            e = enc.engine.embed(wav)
+            e = enc.engine.embed_windows(yd, sd[lo: lo + rows_per_call], win_samples)     # windows read in place: no gathered copy
             idx, _ = ops.sim_argmax(ops.l2norm_rows(e, eps_add=1e-8), cd)
             best.append(idx)
     return torch.cat(best).cpu().numpy().astype(np.int64)

@@ -62,8 +62,6 @@ def build(force: bool = False, verbose: bool = False, stamp: bool = False, varia
     ]
     if stamp:
         common.append("-DSD_STAMP")
-    # experiment knobs for A/B builds on the GPU box (never set for a shipped build): SD_EXTRA_CFLAGS="-DX=1 ..."
-    common += os.environ.get("SD_EXTRA_CFLAGS", "").split()
     procs = []
     objs = []
     for src in SOURCES:

@@ -147,6 +147,8 @@ def cluster_hdbscan(embs: np.ndarray, min_cluster_size: int = 2, clusterer_facto
     HDBSCAN(min_cluster_size, min_samples=None, allow_single_cluster=True, metric="precomputed").fit_predict(D).
     `affinity(X) -> K` lets the caller take the N x N product on the GPU (`ops.cosine_affinity`)."""
     embs = np.asarray(embs)
+    if embs.shape[0] < 2:            # a density clusterer needs two points; one segment is one speaker
+        return np.zeros(embs.shape[0], dtype=int)
     embs_norm = embs / (np.linalg.norm(embs, axis=1, keepdims=True) + 1e-8)
     if affinity is None:
         from sklearn.metrics.pairwise import cosine_similarity as affinity
@@ -156,12 +158,20 @@ def cluster_hdbscan(embs: np.ndarray, min_cluster_size: int = 2, clusterer_facto
     return np.asarray(clu.fit_predict(D))
 
 
-def hdbscan_precomputed(K, min_cluster_size: int = 2, clusterer_factory=None) -> np.ndarray:
-    """HDBSCAN(metric='precomputed') on 1 - K for an affinity that already exists [REF diar_diag.py:214-217]."""
+def hdbscan_precomputed(K, min_cluster_size: int = 2, clusterer_factory=None, min_samples: int | None = None,
+                        allow_single_cluster: bool | None = True) -> np.ndarray:
+    """HDBSCAN(metric='precomputed') on 1 - K for an affinity that already exists.  `allow_single_cluster=None` leaves the
+    clusterer's own default (False), which is what [REF diar_diag.py:214-217] does: HDBSCAN(min_cluster_size=6,
+    min_samples=3, metric='precomputed').  Fewer rows than the clusterer can take -> all noise (-1)."""
     D = 1.0 - _as_f64_affinity(K)
+    n = D.shape[0]
+    if n < 2 or n < (min_samples or min_cluster_size):
+        return np.full(n, 0 if allow_single_cluster else -1, dtype=int)
     factory = clusterer_factory or default_hdbscan_factory
-    return np.asarray(factory(min_cluster_size=min_cluster_size, min_samples=None, allow_single_cluster=True,
-                              metric="precomputed").fit_predict(D))
+    kw = dict(min_cluster_size=min_cluster_size, min_samples=min_samples, metric="precomputed")
+    if allow_single_cluster is not None:
+        kw["allow_single_cluster"] = allow_single_cluster
+    return np.asarray(factory(**kw).fit_predict(D))
 
 
 def cluster_hdbscan_two_stage(embs: np.ndarray, min_cluster_size: int = 2, clusterer_factory=None) -> np.ndarray:
@@ -178,6 +188,8 @@ def cluster_hdbscan_two_stage(embs: np.ndarray, min_cluster_size: int = 2, clust
     """
     embs = np.asarray(embs)
     num_segments = embs.shape[0]
+    if num_segments < 2:             # nothing to cluster: the reference's "no micro-clusters -> speaker 0" outcome [REF :216-218]
+        return np.zeros(num_segments, dtype=int) if num_segments > 0 else np.array([])
     factory = clusterer_factory or default_hdbscan_factory
     settings = dict(min_cluster_size=min_cluster_size, min_samples=None, metric="euclidean", allow_single_cluster=True)
     embs_norm = embs / (np.linalg.norm(embs, axis=1, keepdims=True) + 1e-8)

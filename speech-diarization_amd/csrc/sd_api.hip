@@ -145,7 +145,7 @@ extern "C" int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row
   a.act = SD_ACT_NONE; a.act2 = SD_ACT_NONE;
   // the whole matrix: tiles on and above the diagonal, each stored as is and transposed (half the MFMA work;
   // K[i][j] and K[j][i] are then the same bits).  SD_AFFINITY_SYM=0 (diagnostic) computes every tile.
-  static const bool sym = [] { const char* e = getenv("SD_AFFINITY_SYM"); return !e || atoi(e) != 0; }();
+  static const bool sym = [] { const char* e = sd_experiment_env("SD_AFFINITY_SYM"); return !e || atoi(e) != 0; }();
   if (sym && row_lo == 0 && row_hi == N) return sd_conv1d_cl_f32_symmetric(&a, stream);
   return sd_conv1d_cl_f32(&a, stream);
 }

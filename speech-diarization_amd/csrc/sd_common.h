@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include "sd_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -46,6 +47,13 @@ struct SdProfScope {
 // calling thread's current device, so a second GPU in the same process or two threads racing the first call
 // (the reference's web UI calls the pipeline from a worker thread) both get the attribute set before the launch.
 hipError_t sd_func_max_lds(const void* func, int bytes);
+
+// A/B switches (SD_F32_WIDE, SD_RES2_FUSED, ...) re-route kernels and exist for measurements only: they are read ONLY when the
+// process also sets SD_EXPERIMENT=1, so a stray SD_* variable cannot change which kernels a product run uses.
+static inline const char* sd_experiment_env(const char* name) {
+  static const bool on = [] { const char* e = getenv("SD_EXPERIMENT"); return e && e[0] == '1' && e[1] == 0; }();
+  return on ? getenv(name) : nullptr;
+}
 
 static inline bool sd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

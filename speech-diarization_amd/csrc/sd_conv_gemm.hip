@@ -642,7 +642,7 @@ extern "C" int sd_debug_read_c32_stamps(unsigned long long* out, int n) {
 
 namespace {
 std::atomic<long> g_skinny_below{[] {
-  const char* e = getenv("SD_SKINNY_TILES");
+  const char* e = sd_experiment_env("SD_SKINNY_TILES");
   return e ? atol(e) : 128L;     // measured at 16 / 32 / 64 / 128 segments: 128 beats 256 and 512
 }()};
 }  // namespace
@@ -722,7 +722,7 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
   }
   // wide outputs of large launches: the 256x256 ring kernel (SD_F32_WIDE=0: A/B switch; no tee_add epilogue, column
   // statistics only for tiles that span <= 2 segments, at least four rounds of tiles over the CUs)
-  static const bool wide_ok = [] { const char* e = getenv("SD_F32_WIDE"); return !(e && e[0] == '0'); }();
+  static const bool wide_ok = [] { const char* e = sd_experiment_env("SD_F32_WIDE"); return !(e && e[0] == '0'); }();
   {
     const long t256 = ((a->M + WBM - 1) / WBM) * ((a->cout + WBN - 1) / WBN);
     if (wide_ok && !symmetric && a->cout >= 1024 && t256 >= g_wide_from.load(std::memory_order_relaxed) && t256 > 0 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128)) {
@@ -738,21 +738,21 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
   }
   // SD_F32_DMA=0|1 (diagnostic): operand staging through registers or by LDS-DMA
   static const int dma = [] {
-    const char* e = getenv("SD_F32_DMA");
+    const char* e = sd_experiment_env("SD_F32_DMA");
     return e ? atoi(e) : SD_F32_DMA_DEFAULT;
   }();
   const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);   // the C tile of the epilogue needs BM * LDC <= this
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_kernel<false>), (int)lds));
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_kernel<true>), (int)lds));
   static const int order = [] {
-    const char* e = getenv("SD_TILE_ORDER");
+    const char* e = sd_experiment_env("SD_TILE_ORDER");
     return e ? atoi(e) : 1;
   }();
   // SD_PERSIST=<n> (diagnostic): at most n workgroups walk the tile list instead of one workgroup per
   // tile.  Measured with n = 2 per CU: 2.3 % SLOWER (the dispatcher's dynamic placement beats a static
   // share of the tiles; dispatch gaps are not what separates the kernel from its K-loop rate).
   static const int persist = [] {
-    const char* e = getenv("SD_PERSIST");
+    const char* e = sd_experiment_env("SD_PERSIST");
     return e ? atoi(e) : 0;
   }();
   {

@@ -659,7 +659,7 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   // on the narrow outputs (Res2Net 128x384: 555, 3072->128: 530 vs 408) and is the only one with the
   // tee_add epilogue.  SD_F16_KERNEL=reg|t256 forces one kernel for A/B runs.
   static const int forced = [] {
-    const char* e = getenv("SD_F16_KERNEL");
+    const char* e = sd_experiment_env("SD_F16_KERNEL");
     if (!e) return -1;
     return e[0] == 'r' ? 0 : e[0] == 't' ? 2 : -1;
   }();
@@ -668,7 +668,7 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   // (the 256x256 kernel: no tee_add epilogue, and column statistics only for tiles that span <= 2 segments)
   if (xa && choice == 2 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128)) {
     static const bool direct_ok = [] {     // SD_T256_DIRECT=0: the LDS-staged epilogue for every layer (A/B runs)
-      const char* e = getenv("SD_T256_DIRECT");
+      const char* e = sd_experiment_env("SD_T256_DIRECT");
       return !(e && e[0] == '0');
     }();
     const bool plain = vec && (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg && !a->tee;

@@ -149,14 +149,14 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   const size_t es = dt == SD_DT_F16 ? 2 : 4;
 
   static const bool colstat_ok = [] {     // SD_COLSTAT=0: A/B switch for measurements
-    const char* e = getenv("SD_COLSTAT");
+    const char* e = sd_experiment_env("SD_COLSTAT");
     return !(e && e[0] == '0');
   }();
   // block 0: TDNNBlock(n_mels -> C, k=5) on the f32 features.  f16: the features are rounded to f16 once (the
   // operand precision of that path anyway; t2 is free here), which lets the stem run on the LDS-DMA kernel of the
   // wide layers (-0.75 ms per 5000 segments: 106.6 -> 108.3 k segments/s).  SD_STEM_CAST=0: A/B switch.
   {
-    static const bool cast_ok = [] { const char* e = getenv("SD_STEM_CAST"); return !(e && e[0] == '0'); }();
+    static const bool cast_ok = [] { const char* e = sd_experiment_env("SD_STEM_CAST"); return !(e && e[0] == '0'); }();
     const void* x = feats;
     int xdt = F32;
     if (dt == SD_DT_F16 && cast_ok && ((long)M * w->n_mels) % 8 == 0 && sd_aligned16(feats)) {
@@ -173,7 +173,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // segment's chain state in LDS (sd_res2net_f16.hip); otherwise (f32, or a segment too long for LDS) one conv per
     // step, chunk 1 teed to s0 by tdnn1 and the adds c_{j+1} + y_j produced by each conv's epilogue.
     static const bool chain_ok = [] {     // SD_RES2_FUSED=0: A/B switch for measurements
-      const char* e = getenv("SD_RES2_FUSED");
+      const char* e = sd_experiment_env("SD_RES2_FUSED");
       return !(e && e[0] == '0');
     }();
     const sd_layer& r2 = blk.res2[0];
@@ -242,7 +242,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // asp.conv + softmax over T + weighted statistics: one kernel where the geometry allows (the
     // [M][3C] logits are then never stored), else the conv followed by the pooling kernel
     static const bool fuse_ok = [] {     // SD_ASP_FUSED=0: A/B switch for measurements
-      const char* e = getenv("SD_ASP_FUSED");
+      const char* e = sd_experiment_env("SD_ASP_FUSED");
       return !(e && e[0] == '0');
     }();
     const bool fused = fuse_ok && w->asp_conv.taps == 1 && w->asp_conv.cin_pad == w->att_channels &&

@@ -68,6 +68,7 @@ __device__ __forceinline__ float key_f32(int k) {
 #ifndef SD_FB_SCALE
 #define SD_FB_SCALE 1024.f
 #endif
+#define SD_FB_XMAX 16.0f                            // 2 * 16 * 1024 = 32768 < 65504 (f16 max)
 constexpr int V2_XS_W = 5952;                       // per-wave sample image, floats (two spans + skew + alignment slack)
 constexpr int V2_STAGE_BYTES = 16 * 1024;           // basis fragments of one (pass, k step): 4 tiles x 4 kinds x 1 KB
 constexpr int V2_KSTEPS = 13;                       // 208 / 16
@@ -81,6 +82,8 @@ typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 
 struct Fbank2Args {
   const float* wav; int B; int n; int T;
+  const long long* starts;  // windowed entry: row b = wav[starts[b] .. starts[b] + n), zeros outside [0, n_total); null: row b = wav + b n
+  long long n_total;        // samples behind `wav`
   const _Float16* basis;   // [pass][k step][tile in pass][Chi | Clo | Shi | Slo][64 lanes][8]
   const __bf16* melw;      // [bin tile][k half][mel tile][W1 | W2][64 lanes][8]
   int n_mels; int pad_mode; int log_mode; float log_eps;
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const Fbank2Args p
     // 32 independent loads in flight per lane (a span is ~84 per lane): the wave is alone on its SIMD and the samples come
     // from HBM, so every batch costs a full memory round trip
     constexpr int SB = 32;
-    auto stage_span = [&](const float* src, int s0, int len, int off) {
+    auto stage_span = [&](int b, int s0, int len, int off) {
+      const long long start = p.starts ? p.starts[b] : (long long)b * p.n;      // first sample of row b in `wav`
       for (int rel0 = lane; rel0 < len; rel0 += 64 * SB) {
         float v[SB];
         bool okv[SB];
@@ -241,11 +245,16 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const Fbank2Args p
             ok = sidx >= 0 && sidx < p.n;
           }
           sidx = sidx < 0 ? 0 : (sidx >= p.n ? p.n - 1 : sidx);
+          long long gi = start + sidx;                // a window may hang over either end of the signal: zeros there
+          ok = ok && gi >= 0 && gi < p.n_total;
+          gi = gi < 0 ? 0 : (gi >= p.n_total ? p.n_total - 1 : gi);
           okv[u] = ok;
-          v[u] = src[sidx];
+          v[u] = p.wav[gi];
         }
+        // zero padding, and saturation at +-SD_FB_XMAX: the folded sums x[k] +- x[400-k], scaled by 2^10, must stay inside
+        // the f16 range (|x| <= 16 is exact; beyond it the sample is clipped instead of turning the segment into NaNs)
 #pragma unroll
-        for (int u = 0; u < SB; ++u) v[u] = okv[u] ? v[u] : 0.f;
+        for (int u = 0; u < SB; ++u) v[u] = okv[u] ? __builtin_amdgcn_fmed3f(v[u], -SD_FB_XMAX, SD_FB_XMAX) : 0.f;
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
           const int rel = rel0 + 64 * u;
@@ -253,8 +262,8 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const Fbank2Args p
         }
       }
     };
-    stage_span(p.wav + (size_t)bA * p.n, tA * HOP - NFFT / 2, lenA, 0);
-    if (nfB > 0) stage_span(p.wav + (size_t)(bA + 1) * p.n, -NFFT / 2, (nfB - 1) * HOP + NFFT, offB);
+    if (nfA > 0) stage_span(bA, tA * HOP - NFFT / 2, lenA, 0);
+    if (nfB > 0) stage_span(bA + 1, -NFFT / 2, (nfB - 1) * HOP + NFFT, offB);
   }
   const int j = lane & 31, h = lane >> 5;
   int base;                                           // word of this lane's frame start
@@ -464,9 +473,25 @@ extern "C" size_t sd_fbank_workspace_bytes(const sd_fbank_plan*, int B, int) {
   return ((size_t)(B > 0 ? B : 0) * sizeof(int) + 255) & ~(size_t)255;
 }
 
+static int fbank_launch(const sd_fbank_plan* plan, const float* wav_dev, long long n_total, const long long* starts_dev, int B, int n,
+                        int mean_norm, float* out_dev, int ld_out, void* ws_dev, size_t ws_bytes, sd_stream_t stream_);
+
 extern "C" int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int B, int n,
                             int mean_norm, float* out_dev, int ld_out,
                             void* ws_dev, size_t ws_bytes, sd_stream_t stream_) {
+  return fbank_launch(plan, wav_dev, (long long)B * n, nullptr, B, n, mean_norm, out_dev, ld_out, ws_dev, ws_bytes, stream_);
+}
+
+extern "C" int sd_fbank_windows_f32(const sd_fbank_plan* plan, const float* wav_dev, long long n_total, const long long* starts_dev,
+                                    int B, int n, int mean_norm, float* out_dev, int ld_out,
+                                    void* ws_dev, size_t ws_bytes, sd_stream_t stream_) {
+  SD_CHECK_ARG(n_total >= 1, "sd_fbank_windows_f32: n_total=%lld", n_total);
+  SD_CHECK_ARG(B == 0 || starts_dev != nullptr, "sd_fbank_windows_f32: null starts");
+  return fbank_launch(plan, wav_dev, n_total, starts_dev, B, n, mean_norm, out_dev, ld_out, ws_dev, ws_bytes, stream_);
+}
+
+static int fbank_launch(const sd_fbank_plan* plan, const float* wav_dev, long long n_total, const long long* starts_dev, int B, int n,
+                        int mean_norm, float* out_dev, int ld_out, void* ws_dev, size_t ws_bytes, sd_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SD_CHECK_ARG(plan != nullptr, "sd_fbank_f32: null plan");
   SD_CHECK_ARG(B >= 0 && n >= 0, "sd_fbank_f32: B=%d n=%d", B, n);
@@ -483,6 +508,7 @@ extern "C" int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int
   const int T = 1 + n / HOP;
   Fbank2Args a;
   a.wav = wav_dev; a.B = B; a.n = n; a.T = T;
+  a.starts = starts_dev; a.n_total = n_total;
   a.basis = static_cast<const _Float16*>(plan->basis16_dev); a.melw = static_cast<const __bf16*>(plan->melw16_dev);
   a.n_mels = plan->n_mels; a.pad_mode = plan->pad_mode; a.log_mode = plan->log_mode; a.log_eps = plan->log_eps;
   a.out = out_dev; a.ld_out = ld_out;

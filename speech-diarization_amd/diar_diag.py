@@ -41,18 +41,22 @@ def asnorm_scores(query_embs: np.ndarray, ref_centers: np.ndarray, cohort_embs: 
     return 0.5 * (zq + zr)
 
 
-def cluster_embeddings(embs: np.ndarray, method: str = "hdbscan", cos_thr: float = 0.68) -> np.ndarray:
-    """"agglo": average-linkage AHC on 1 - cosine cut at 1 - cos_thr; "hdbscan": HDBSCAN(min_cluster_size=6,
-    metric="precomputed") on 1 - cosine (`cluster.default_hdbscan_factory`) [REF diar_diag.py:213-229].
-    The N x N cosine runs on the GPU."""
-    import torch
-    from . import ops
-    K = ops.cosine_affinity(torch.from_numpy(np.ascontiguousarray(embs, dtype=np.float32)).cuda()).cpu().numpy()
+def cluster_embeddings(embs: np.ndarray, method: str = "hdbscan", cos_thr: float = 0.68, affinity=None, clusterer_factory=None) -> np.ndarray:
+    """"agglo": average-linkage AHC on 1 - cosine cut at 1 - cos_thr; "hdbscan": HDBSCAN(min_cluster_size=6, min_samples=3,
+    metric="precomputed") on 1 - cosine, `allow_single_cluster` left at the clusterer's default [REF diar_diag.py:213-229]
+    (`cluster.default_hdbscan_factory` unless `clusterer_factory` is given).  The N x N cosine runs on the GPU
+    (`ops.cosine_affinity`) unless `affinity(embs) -> K` is injected (CPU tests)."""
+    if method not in ("hdbscan", "agglo"):
+        raise ValueError("method must be 'hdbscan' or 'agglo'")
+    if affinity is None:
+        import torch
+        from . import ops
+        K = ops.cosine_affinity(torch.from_numpy(np.ascontiguousarray(embs, dtype=np.float32)).cuda()).cpu().numpy()
+    else:
+        K = np.asarray(affinity(embs))
     if method == "agglo":
         return ahc_cosine(K, cos_thr)
-    if method == "hdbscan":
-        return hdbscan_precomputed(K, min_cluster_size=6)
-    raise ValueError("method must be 'hdbscan' or 'agglo'")
+    return hdbscan_precomputed(K, min_cluster_size=6, clusterer_factory=clusterer_factory, min_samples=3, allow_single_cluster=None)
 
 
 def viterbi_hmm(scores: np.ndarray, alpha: float = 0.995, device=None) -> np.ndarray:

@@ -175,7 +175,7 @@ def diarize_audio(audio_filepath: str | Path | dict, min_speech_duration_s: floa
         win = int(round(window_s * sr))
         starts, centres, regions = speech_windows(speech, len(y), sr, window_s, hop_s)
         if world is None:
-            embs = encoder(gather_windows(y, starts, win))
+            embs = _embed_windows(encoder, y, starts, win, use_gpu)
         elif world == "dist":
             embs = _embed_sharded(encoder, y, starts, win, use_gpu)
         else:
@@ -204,18 +204,29 @@ def _rank() -> int:
     return dist.world()[0]
 
 
+def _embed_windows(encoder: Encoder, y: np.ndarray, starts: np.ndarray, win: int, use_gpu: bool, to_host: bool = True):
+    """[len(starts), 192] embeddings of the windows y[s : s + win] (zero padded past the end).  HIP encoder: the signal is
+    uploaded ONCE and the fbank kernel reads the windows in place (`sd_fbank_windows_f32`; a 1 h meeting at 2 s / 0.25 s is
+    230 MB of signal instead of 1.8 GB of gathered, 8x overlapping windows).  Injected encoder (configs[0], tests): the
+    literal host gather the reference's callers do."""
+    if use_gpu:
+        from .speech_encode import using_ecapa_encoder
+        return using_ecapa_encoder().encode_windows(y, starts, win, to_host=to_host)
+    return encoder(gather_windows(y, starts, win)) if len(starts) else np.zeros((0, 192), np.float32)
+
+
 def _embed_sharded(encoder: Encoder, y: np.ndarray, starts: np.ndarray, win: int, use_gpu: bool) -> np.ndarray:
     """Embed this rank's round-robin shard of the windows, all-gather the 192-d rows (RCCL when the process
-    group is "nccl": device tensors; gloo: host tensors), return all N rows in window order."""
+    group is "nccl": device tensors; gloo: host tensors), return all N rows in window order.  With the HIP encoder
+    the embeddings stay on the device from the forward through the collective: one D2H of [N, 192] at the end."""
     import torch
     from . import dist
     rank, w = dist.world()
     n = len(starts)
     mine = dist.shard_indices(n, rank, w)
-    local = encoder(gather_windows(y, starts[mine], win)) if len(mine) else np.zeros((0, 192), np.float32)
-    t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
-    if use_gpu and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl":
-        t = t.cuda()
+    on_device = use_gpu and (not torch.distributed.is_initialized() or torch.distributed.get_backend() == "nccl")
+    local = _embed_windows(encoder, y, starts[mine], win, use_gpu, to_host=not on_device)
+    t = local if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
     return dist.all_gather_embeddings(t, n).cpu().numpy()
 
 

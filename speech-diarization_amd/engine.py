@@ -206,11 +206,66 @@ class EmbeddingEngine:
                                       ec_ws.data_ptr(), ec_ws.numel(), stream), f"sd_ecapa_forward_{self.precision}")
         return out
 
+    def embed_windows(self, signal: torch.Tensor, starts: torch.Tensor, n: int) -> torch.Tensor:
+        """Embeddings of the B windows `signal[starts[b] : starts[b] + n]` of ONE recording (zeros where a window hangs
+        over an end of the signal), without gathering them: `sd_fbank_windows_f32` reads the resident signal at
+        `starts[b]`, so the recording crosses PCIe once and no [B, n] matrix is written to and re-read from HBM.
+        Bitwise `embed(gathered windows)`.  signal: f32 [n_total] on the device; starts: int64 [B] (any device);
+        -> f32 [B, dim] on the device.  [REF anti_stick_diarize.py:82-100, 396-430]: the callers' window loops."""
+        if signal.dim() != 1:
+            raise AssertionError("signal must be [n_total]")
+        if signal.device != self.device:
+            raise ValueError(f"signal is on {signal.device}, engine on {self.device}")
+        signal = signal.contiguous().float()
+        starts = starts.to(self.device, dtype=torch.int64).contiguous()
+        B, n = int(starts.numel()), int(n)
+        out = torch.empty((B, self.dim), dtype=torch.float32, device=self.device)
+        if B == 0:
+            return out
+        if n < 5 * 160:
+            raise ValueError(f"window of {n} samples is too short: ECAPA's reflect padding needs at least 5 frames (800 samples)")
+        if signal.numel() < 1:
+            raise ValueError("empty signal")
+        with self._lock, torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            mb = min(self.max_batch, B)
+            feats, fb_ws, ec_ws = self._workspace(mb, n)
+            T = FbankPlan.num_frames(n)
+            W = C.byref(self.weights.struct)
+            for lo in range(0, B, mb):
+                nb = min(mb, B - lo)
+                N.check(self._lib.sd_fbank_windows_f32(self.plan.handle, signal.data_ptr(), signal.numel(), starts[lo:lo + nb].data_ptr(),
+                                                       nb, n, 1, feats.data_ptr(), self.weights.cfg.input_size,
+                                                       fb_ws.data_ptr(), fb_ws.numel(), stream), "sd_fbank_windows_f32")
+                N.check(self._forward(W, feats.data_ptr(), nb, T, out[lo:lo + nb].data_ptr(),
+                                      ec_ws.data_ptr(), ec_ws.numel(), stream), f"sd_ecapa_forward_{self.precision}")
+        return out
+
     def features(self, wav: torch.Tensor) -> torch.Tensor:
         """The mean-normalised fbank the network consumes, [B, T, n_mels] (diagnostics / tests)."""
         wav = wav.contiguous().float()
         B, n = wav.shape
         return fbank_device(wav, self.plan, mean_norm=True)
+
+
+def fbank_windows_device(signal: torch.Tensor, starts: torch.Tensor, n: int, plan: FbankPlan, mean_norm: bool = True) -> torch.Tensor:
+    """HIP fbank of the windows signal[starts[b] : starts[b] + n] of one device-resident recording -> [B, T, n_mels]."""
+    if signal.dim() != 1 or signal.device.type != "cuda":
+        raise RuntimeError("fbank_windows_device needs a 1-d GPU tensor; there is no CPU fallback")
+    lib = N.load()
+    signal = signal.contiguous().float()
+    starts = starts.to(signal.device, dtype=torch.int64).contiguous()
+    B = int(starts.numel())
+    T = FbankPlan.num_frames(n)
+    out = torch.empty((B, T, plan.n_mels), dtype=torch.float32, device=signal.device)
+    if B == 0:
+        return out
+    with torch.cuda.device(signal.device):
+        ws = torch.empty((max(plan.workspace_bytes(B, n), 256),), dtype=torch.uint8, device=signal.device)
+        stream = C.c_void_p(torch.cuda.current_stream(signal.device).cuda_stream)
+        N.check(lib.sd_fbank_windows_f32(plan.handle, signal.data_ptr(), signal.numel(), starts.data_ptr(), B, int(n), int(bool(mean_norm)),
+                                         out.data_ptr(), plan.n_mels, ws.data_ptr(), ws.numel(), stream), "sd_fbank_windows_f32")
+    return out
 
 
 def fbank_device(wav: torch.Tensor, plan: FbankPlan, mean_norm: bool = True) -> torch.Tensor:

@@ -3,7 +3,9 @@
 Same callables, same array conventions (numpy in, fresh numpy out, `assert wavs.ndim == 2`):
 
 * `fbank_batch(wavs, sr, n_mels, mean_nor)`          [REF speech_encode.py:10-38]
-* `using_ecapa_encoder(device)` (lru_cache singleton)  [REF speech_encode.py:64-70]
+* `using_ecapa_encoder(device)` (lru_cache singleton)  [REF speech_encode.py:64-70]; its arithmetic ("f32" | "f16") is the
+  process-wide switch `set_precision()` / env `SD_ECAPA_PRECISION`, cf. the reference's global precision knob
+  [REF diarization_baseline.py:20-21]
 * `ecapa_encode_batch(wavs)`                           [REF speech_encode.py:73-78]
 * `using_eres2netv2_encoder()` / `eres2netv2_encode_batch(...)` [REF speech_encode.py:42-60]
 
@@ -29,6 +31,31 @@ from .features import FbankPlan
 _THIS_DIR = Path(__file__).parent.resolve()
 ECAPA_SOURCE = "LanceaKing/spkrec-ecapa-cnceleb"  # [REF speech_encode.py:67]
 SYNTHETIC_SEED = 1234
+
+# Arithmetic of the ECAPA-TDNN forward behind `using_ecapa_encoder()`: "f32" (exact f32 MFMA, the reference CPU path's
+# arithmetic) or "f16" (f16 operands, f32 accumulation: BASELINE.json configs[4]).  A process-wide switch, like the
+# reference's own precision knob (`torch.backends.cuda.matmul.allow_tf32 = True`, [REF diarization_baseline.py:20-21]);
+# initial value from the environment variable SD_ECAPA_PRECISION.
+_PRECISIONS = ("f32", "f16")
+_precision = os.environ.get("SD_ECAPA_PRECISION", "f32").lower()
+if _precision not in _PRECISIONS:
+    raise ValueError(f"SD_ECAPA_PRECISION must be one of {_PRECISIONS}, got {_precision!r}")
+
+
+def get_precision() -> str:
+    return _precision
+
+
+def set_precision(precision: str) -> None:
+    """Select the arithmetic of the encoder singleton ("f32" | "f16"); drops the cached encoder so that the next
+    `using_ecapa_encoder()` / `ecapa_encode_batch()` call builds one with the new setting."""
+    global _precision
+    if precision not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {_PRECISIONS}, got {precision!r}")
+    if precision != _precision:
+        _precision = precision
+        if hasattr(using_ecapa_encoder, "cache_clear"):
+            using_ecapa_encoder.cache_clear()
 
 
 def _cuda_device(device) -> torch.device:
@@ -95,9 +122,10 @@ def load_ecapa_state_dict(path: str | os.PathLike | None = None) -> dict:
 class HipEcapaEncoder:
     """Stands in for speechbrain's `EncoderClassifier`: `.encode_batch(wavs) -> Tensor[B, 1, 192]`."""
 
-    def __init__(self, state_dict: dict, device, max_batch: int = 512):
+    def __init__(self, state_dict: dict, device, max_batch: int = 512, precision: str = "f32"):
         self.device = _cuda_device(device)
-        self.engine = EmbeddingEngine(state_dict, self.device, max_batch=max_batch)
+        self.precision = precision
+        self.engine = EmbeddingEngine(state_dict, self.device, max_batch=max_batch, precision=precision)
         self.embedding_dim = self.engine.dim
 
     @torch.inference_mode()
@@ -114,12 +142,26 @@ class HipEcapaEncoder:
 
     __call__ = encode_batch
 
+    @torch.inference_mode()
+    def encode_windows(self, signal, starts, n: int, rows_per_call: int = 8192, to_host: bool = True):
+        """Embeddings [B, 192] of the windows `signal[starts[b] : starts[b] + n]` of one recording — what the reference's
+        callers compute by slicing windows on the host and calling `ecapa_encode_batch` on batches of them
+        [REF anti_stick_diarize.py:82-100, 396-430] — with ONE upload of the signal and no gathered copy
+        (`EmbeddingEngine.embed_windows`).  signal: 1-d float array or tensor (host or device); starts: int array."""
+        sig = signal if isinstance(signal, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(signal, dtype=np.float32))
+        sig = sig.to(self.device, dtype=torch.float32, non_blocking=True)
+        st = starts if isinstance(starts, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int64))
+        st = st.to(self.device, dtype=torch.int64)
+        parts = [self.engine.embed_windows(sig, st[lo:lo + rows_per_call], n) for lo in range(0, int(st.numel()), rows_per_call)]
+        out = torch.cat(parts) if parts else torch.empty((0, self.embedding_dim), dtype=torch.float32, device=self.device)
+        return out.cpu().numpy() if to_host else out
+
 
 @lru_cache(maxsize=1)
 def using_ecapa_encoder(device: str | int = "cuda") -> HipEcapaEncoder:
     if not torch.cuda.is_available():
         raise RuntimeError("using_ecapa_encoder: no GPU visible; the HIP path has no CPU fallback")
-    return HipEcapaEncoder(load_ecapa_state_dict(), device)
+    return HipEcapaEncoder(load_ecapa_state_dict(), device, precision=_precision)
 
 
 def ecapa_encode_batch(wavs: np.ndarray) -> np.ndarray:

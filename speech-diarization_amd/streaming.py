@@ -19,20 +19,43 @@ from .engine import EmbeddingEngine
 
 
 class StreamingEmbedder:
+    """The last `window_s` of every channel live in ONE device buffer that is written in place: a doubled ring
+    ([channels, 2 * win]; a hop is stored at q and at q + win, so the newest window is always the contiguous span
+    starting at (q + hop) mod win).  The fbank kernel reads the windows where they lie (`sd_fbank_windows_f32` with a
+    per-channel start offset held in a small device array), so a hop costs two hop-sized copies and no allocation;
+    the captured graph replays against the same buffer and start array (its launches hold their addresses)."""
+
     def __init__(self, engine: EmbeddingEngine, channels: int = 16, window_s: float = 2.0, hop_s: float = 0.25, sr: int = 16000,
                  use_graph: bool = True):
         self.engine = engine
         self.channels, self.sr = channels, sr
         self.win = int(round(window_s * sr))
         self.hop = int(round(hop_s * sr))
+        if self.win % self.hop:
+            raise ValueError(f"window ({self.win} samples) must be a whole number of hops ({self.hop})")
         dev = engine.device
-        self.ring = torch.zeros((channels, self.win), dtype=torch.float32, device=dev)      # last window_s per channel
-        self._static_in = torch.zeros((channels, self.win), dtype=torch.float32, device=dev)
+        self._cap = 2 * self.win
+        self._buf = torch.zeros((channels, self._cap), dtype=torch.float32, device=dev)
+        self._phases = self.win // self.hop
+        base = torch.arange(channels, dtype=torch.int64) * self._cap
+        # window start of every channel in the flat buffer, for each of the win / hop ring phases
+        self._start_table = torch.stack([base + ((ph + 1) * self.hop) % self.win for ph in range(self._phases)]).to(dev)
+        self._starts = self._start_table[self._phases - 1].clone()      # static address (captured by the graph)
+        self._phase = 0
         self._static_out = None
         self._graph = None
         self.use_graph = use_graph
         if use_graph:
             self._capture()
+
+    @property
+    def ring(self) -> torch.Tensor:
+        """The current windows as a [channels, win] tensor (a gathered copy: diagnostics and tests only)."""
+        idx = self._starts[:, None] + torch.arange(self.win, device=self._buf.device)[None, :]
+        return self._buf.view(-1)[idx]
+
+    def _embed(self) -> torch.Tensor:
+        return self.engine.embed_windows(self._buf.view(-1), self._starts, self.win)
 
     def _capture(self) -> None:
         dev = self.engine.device
@@ -40,23 +63,26 @@ class StreamingEmbedder:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(2):                     # warm-up outside capture: allocates the engine workspace
-                self.engine.embed(self._static_in)
+                self._embed()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._static_out = self.engine.embed(self._static_in)
+            self._static_out = self._embed()
         self.engine.freeze_workspace()
 
     def push(self, chunk: torch.Tensor) -> torch.Tensor:
         """chunk: f32 [channels, hop samples] (device or host) -> embeddings [channels, 192] of the updated windows."""
         if chunk.shape != (self.channels, self.hop):
             raise ValueError(f"expected a [{self.channels}, {self.hop}] hop, got {tuple(chunk.shape)}")
-        chunk = chunk.to(self.ring.device, dtype=torch.float32, non_blocking=True)
-        self.ring = torch.cat((self.ring[:, self.hop:], chunk), dim=1)
+        chunk = chunk.to(self._buf.device, dtype=torch.float32, non_blocking=True)
+        q = self._phase * self.hop
+        self._buf[:, q:q + self.hop].copy_(chunk)                        # in place, both images of the ring
+        self._buf[:, q + self.win:q + self.win + self.hop].copy_(chunk)
+        self._starts.copy_(self._start_table[self._phase])
+        self._phase = (self._phase + 1) % self._phases
         if self._graph is None:
-            return self.engine.embed(self.ring)
-        self._static_in.copy_(self.ring)
+            return self._embed()
         self._graph.replay()
         return self._static_out
 

@@ -287,6 +287,24 @@ def main():
                        labels_dtype=str(np.asarray(labels).dtype)))
     out["cluster_two_stage"] = cl
 
+    # ---- diar_diag.cluster_embeddings [REF diar_diag.py:213-229]: the same two stand-ins in the `hdbscan.HDBSCAN` slot
+    # (scripted: pins the constructor arguments and the distance matrix; scikit-learn: labels through a real clusterer),
+    # plus the "agglo" branch, which runs on the scikit-learn that is installed.
+    ce = []
+    e = embs_for(51, [8, 7, 6], dim=24, spread=0.5)
+    rdd.hdbscan.HDBSCAN = Scripted
+    Scripted.script, Scripted.log = [[0] * 8 + [1] * 7 + [-1] * 6], []
+    labels = rdd.cluster_embeddings(e, method="hdbscan")
+    ce.append(dict(name="scripted", method="hdbscan", embs=e, calls=list(Scripted.log), labels=np.asarray(labels)))
+    rdd.hdbscan.HDBSCAN = SkHDBSCAN
+    for seed, sizes in [(52, [14, 12, 9]), (53, [30]), (54, [7, 7, 3])]:
+        e = embs_for(seed, sizes, dim=24, spread=0.6)
+        ce.append(dict(name=f"sklearn_{seed}", method="hdbscan", embs=e, labels=np.asarray(rdd.cluster_embeddings(e, method="hdbscan"))))
+    for seed, sizes, thr in [(55, [10, 8, 6], 0.68), (56, [9, 9], 0.3)]:
+        e = embs_for(seed, sizes, dim=24, spread=0.8)
+        ce.append(dict(name=f"agglo_{seed}", method="agglo", cos_thr=thr, embs=e, labels=np.asarray(rdd.cluster_embeddings(e, method="agglo", cos_thr=thr))))
+    out["cluster_embeddings"] = ce
+
     for name, payload in out.items():
         with open(os.path.join(HERE, f"{name}.json"), "w") as f:
             json.dump(jsonable(payload), f)

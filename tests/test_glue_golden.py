@@ -235,3 +235,59 @@ def test_cluster_two_stage_with_injected_ahc_separates_speakers():
     embs = np.concatenate(rows)
     labels = cluster.cluster_hdbscan_two_stage(embs, 2, clusterer_factory=cluster.AhcClusterer.factory(0.7))
     assert len(set(labels.tolist())) == 3 and all(len(set(labels[10 * k: 10 * k + 10].tolist())) == 1 for k in range(3))
+
+
+def test_cluster_embeddings_matches_reference(golden_dir):
+    """`diar_diag.cluster_embeddings` [REF diar_diag.py:213-229]: constructor arguments (min_cluster_size=6, min_samples=3,
+    allow_single_cluster NOT passed), the 1 - cosine matrix, and labels through scikit-learn's HDBSCAN / AHC."""
+    from sklearn.cluster import HDBSCAN
+    from sklearn.metrics.pairwise import cosine_similarity
+    from speech_diarization_amd import diar_diag
+    for c in _load(golden_dir, "cluster_embeddings"):
+        embs = np.asarray(c["embs"], dtype=np.float64)
+        want = np.asarray(c["labels"], dtype=np.int64)
+        if c["name"] == "scripted":
+            script, log = [list(want)], []
+            got = diar_diag.cluster_embeddings(embs, "hdbscan", affinity=cosine_similarity,
+                                               clusterer_factory=lambda **kw: _Scripted(script, log, **kw))
+            assert np.array_equal(got, want) and len(log) == 1 == len(c["calls"])
+            assert log[0]["kwargs"] == c["calls"][0]["kwargs"] == dict(min_cluster_size=6, min_samples=3, metric="precomputed")
+            np.testing.assert_allclose(log[0]["X"], np.asarray(c["calls"][0]["X"]), rtol=0, atol=1e-12)
+        elif c["method"] == "hdbscan":
+            got = diar_diag.cluster_embeddings(embs, "hdbscan", affinity=cosine_similarity, clusterer_factory=lambda **kw: HDBSCAN(**kw))
+            assert np.array_equal(got, want), c["name"]
+            assert np.array_equal(diar_diag.cluster_embeddings(embs, "hdbscan", affinity=cosine_similarity), want)   # default factory
+        else:
+            got = diar_diag.cluster_embeddings(embs, "agglo", c["cos_thr"], affinity=cosine_similarity)
+            assert np.array_equal(got, want), c["name"]
+    with pytest.raises(ValueError):
+        diar_diag.cluster_embeddings(np.zeros((3, 4)), "kmeans", affinity=cosine_similarity)
+
+
+def test_clustering_small_inputs_do_not_raise():
+    """One post-SCD segment (or none) is one speaker, not a ValueError from the density clusterer."""
+    from speech_diarization_amd import cluster
+    e1 = np.ones((1, 8))
+    assert cluster.cluster_hdbscan_two_stage(e1).tolist() == [0]
+    assert cluster.cluster_hdbscan_two_stage(np.zeros((0, 8))).size == 0
+    assert cluster.cluster_hdbscan(e1).tolist() == [0]
+    assert cluster.cluster_hdbscan(np.zeros((0, 8))).size == 0
+    assert cluster.hdbscan_precomputed(np.ones((1, 1))).tolist() == [0]
+    assert cluster.hdbscan_precomputed(np.ones((4, 4)), min_cluster_size=6, min_samples=3, allow_single_cluster=None).tolist() == [-1] * 4
+    two = np.array([[1.0, 0.0], [0.0, 1.0]])
+    assert len(cluster.cluster_hdbscan_two_stage(two)) == 2
+
+
+def test_diarize_with_a_single_segment_returns_one_speaker():
+    """diarize() on a recording whose VAD gives ONE short segment must not crash in the clusterer."""
+    rng = np.random.default_rng(0)
+    y = (0.1 * rng.standard_normal(16000 * 3)).astype(np.float32)
+
+    def encode(w):
+        w = np.asarray(w, dtype=np.float32)
+        return np.stack([np.abs(np.fft.rfft(r, 382))[:192] for r in w]).astype(np.float32)
+
+    segs = asd.diarize(y, vad_segments=lambda *a, **k: [(0.5, 1.4)], encode=encode, reseg=0)
+    assert len(segs) == 1 and segs[0].spk == 0 and (segs[0].start, segs[0].end) == (0.5, 1.4)
+    segs = asd.diarize(y, vad_segments=lambda *a, **k: [(0.5, 1.4)], encode=encode, reseg=1)
+    assert all(s.spk == 0 for s in segs)

@@ -36,3 +36,51 @@ def test_checkpoint_through_env_var_and_singleton_gives_the_in_memory_engine_bit
             speech_encode.load_ecapa_state_dict()
     finally:
         speech_encode.using_ecapa_encoder.cache_clear()
+
+
+def _cos_dist(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+def test_precision_switch_reaches_the_drop_in_api(dev, tmp_path):
+    """BASELINE configs[4] ("fp16 ECAPA") through the reference's names: `set_precision("f16")` (or the environment
+    variable SD_ECAPA_PRECISION) makes `using_ecapa_encoder()` / `ecapa_encode_batch()` / `diarize_audio()` run the f16
+    engine — the process-wide switch the reference has for its own precision knob [REF diarization_baseline.py:20-21]."""
+    import os
+    import subprocess
+    import sys
+    from speech_diarization_amd import audio_io, diarization_baseline as db, speech_encode, synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    wav = synth.synthetic_segments(3, 6, 32000)
+    assert speech_encode.get_precision() == "f32"
+    speech_encode.using_ecapa_encoder.cache_clear()
+    try:
+        with pytest.warns(RuntimeWarning):
+            e32 = speech_encode.ecapa_encode_batch(wav)
+        assert speech_encode.using_ecapa_encoder().engine.precision == "f32"
+        speech_encode.set_precision("f16")
+        with pytest.warns(RuntimeWarning):
+            enc = speech_encode.using_ecapa_encoder()
+        assert enc.precision == "f16" and enc.engine.precision == "f16" and speech_encode.using_ecapa_encoder() is enc
+        e16 = speech_encode.ecapa_encode_batch(wav)
+        sd = synth.make_ecapa_state_dict(speech_encode.SYNTHETIC_SEED)      # what the singleton loads when no checkpoint is present
+        direct = EmbeddingEngine(sd, dev, precision="f16").embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+        assert np.array_equal(e16, direct)                       # it IS the f16 engine
+        assert not np.array_equal(e16, e32) and _cos_dist(e16, e32).max() < 1e-3
+        conv = synth.synthetic_conversation(30.0, 2, seed=0)
+        p = tmp_path / "m.wav"
+        audio_io.write_wav16(p, conv.wav, conv.sr)
+        _, det = db.diarize_audio(p, 0.35, 0.1, 2, 6, return_details=True)
+        ref = enc.encode_windows(audio_io.read_audio(p, sr=16000, mono=True)[0], det["window_starts"], 32000)
+        assert np.array_equal(det["embeddings"], ref)
+        with pytest.raises(ValueError):
+            speech_encode.set_precision("bf16")
+    finally:
+        speech_encode.set_precision("f32")
+        speech_encode.using_ecapa_encoder.cache_clear()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, warnings; sys.path.insert(0, %r); warnings.simplefilter('ignore'); from speech_diarization_amd import speech_encode as s; "
+            "print(s.get_precision(), s.using_ecapa_encoder().engine.precision)") % root
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, SD_ECAPA_PRECISION="f16"))
+    assert res.returncode == 0 and res.stdout.split() == ["f16", "f16"], res.stderr[-1500:]

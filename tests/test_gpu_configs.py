@@ -127,6 +127,10 @@ def test_config3_streaming_graph_replay_matches_eager(dev):
         b = eager.push(chunk)
         assert a.shape == (16, 192)
         assert torch.equal(a, b)                        # same kernels, same order: bitwise equal
+        want = np.zeros((16, 32000), np.float32)        # the ring holds the last 2 s of every channel, oldest first
+        have = feed[:, max(0, (h + 1) * 4000 - 32000):(h + 1) * 4000]
+        want[:, 32000 - have.shape[1]:] = have
+        assert np.array_equal(st.ring.cpu().numpy(), want)
     print(f"streaming hop latency (small geometry): p50 {np.median(lat) * 1e3:.3f} ms")
     with pytest.raises(ValueError):
         st.push(torch.zeros(16, 100))
@@ -134,6 +138,105 @@ def test_config3_streaming_graph_replay_matches_eager(dev):
     x = np.eye(192)[:3]
     labels = oc.assign(np.concatenate([x, x + 0.01, x[:1]]))
     assert labels.tolist() == [0, 1, 2, 0, 1, 2, 0]
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-5), ("f16", 1e-3)])
+def test_config3_streaming_full_geometry_matches_the_oracle(dev, precision, tol):
+    """BASELINE configs[3] at the real geometry (C = 1024 spkrec-ecapa state dict, 16 channels x 2 s windows, 250 ms hop,
+    hipGraph-captured fbank + ECAPA per hop), 11 hops: the graph-replayed embeddings are (a) bitwise the eager embeddings of
+    the same ring, (b) bitwise `engine.embed` of the ring contents, and (c) the float64 oracle's embeddings of those
+    contents (`oracle.pipeline_ref.encode_batch_ref`, the call being replaced is [REF speech_encode.py:73-78]): hop 2 (ring
+    still mostly zeros) on 4 channels, hop 10 (ring wrapped) on all 16."""
+    from oracle.pipeline_ref import encode_batch_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    from speech_diarization_amd.streaming import StreamingEmbedder
+    sd = synth.make_ecapa_state_dict(1234)
+    st = StreamingEmbedder(EmbeddingEngine(sd, dev, max_batch=16, precision=precision), channels=16, window_s=2.0, hop_s=0.25)
+    eager = StreamingEmbedder(EmbeddingEngine(sd, dev, max_batch=16, precision=precision), channels=16, use_graph=False)
+    plain = EmbeddingEngine(sd, dev, max_batch=16, precision=precision)
+    feed = synth.synthetic_segments(51, 16, 4000 * 11)
+    worst = 0.0
+    for h in range(11):
+        chunk = torch.from_numpy(feed[:, h * 4000:(h + 1) * 4000]).to(dev)
+        a = st.push(chunk).clone()
+        assert torch.equal(a, eager.push(chunk))
+        ring = st.ring
+        assert torch.equal(a, plain.embed(ring))
+        if h in (2, 10):
+            rows = slice(0, 4) if h == 2 else slice(0, 16)
+            ref = encode_batch_ref(sd, ring[rows].cpu().numpy(), torch.float64)
+            e = a[rows].cpu().numpy().astype(np.float64)
+            cd = 1.0 - (e * ref).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(ref, axis=1))
+            worst = max(worst, float(cd.max()))
+            assert cd.max() < tol, (precision, h, cd)
+    print(f"configs[3] full geometry, {precision}: max cosine distance to the float64 oracle {worst:.2e}")
+
+
+def test_config2_one_hour_meeting_through_the_product_entry(tmp_path):
+    """BASELINE configs[2] through `diarize_audio(world="dist")` [REF diarization_baseline.py:236-266] at full geometry on the
+    GPU: a synthetic 1 h, 8-voice meeting; the sharded entry under RCCL (process group "nccl" in a world of one — the box
+    has one card — with the all-gather forced) writes the RTTM of the unsharded call byte for byte, the embeddings never
+    leave the device before the collective, and cluster labels computed from the GPU embeddings equal those computed from
+    the CPU oracle's embeddings on a subsample of the windows.  Runs in a fresh process (it owns a process group)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import os, sys, time, warnings
+sys.path.insert(0, {root!r})
+warnings.simplefilter("ignore")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", SD_DIST_FORCE_COLLECTIVE="1")
+import numpy as np, torch, torch.distributed as tdist
+from oracle.ecapa_ref import EcapaRef
+from oracle.pipeline_ref import encode_batch_ref
+from speech_diarization_amd import audio_io, cluster, diarization_baseline as db, ops, speech_encode, synth
+t0 = time.time()
+conv = synth.synthetic_conversation(3600.0, 8, seed=0)
+wav = {str(tmp_path)!r} + "/meeting.wav"
+audio_io.write_wav16(wav, conv.wav, conv.sr)
+print(f"meeting generated in {{time.time() - t0:.1f}} s", flush=True)
+torch.cuda.set_device(0)
+t0 = time.time()
+seg1, det1 = db.diarize_audio(wav, 0.35, 0.1, 2, 8, rttm_filepath=wav[:-4] + ".single.rttm", return_details=True)
+print(f"world=None: {{det1['embeddings'].shape[0]}} windows, {{len(seg1)}} turns, {{time.time() - t0:.1f}} s", flush=True)
+tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+calls = []
+orig = tdist.all_gather_into_tensor
+def spy(out, inp, *a, **k):
+    calls.append((tuple(inp.shape), inp.is_cuda, out.is_cuda))
+    return orig(out, inp, *a, **k)
+tdist.all_gather_into_tensor = spy
+t0 = time.time()
+seg2, det2 = db.diarize_audio(wav, 0.35, 0.1, 2, 8, rttm_filepath=wav[:-4] + ".dist.rttm", return_details=True, world="dist")
+print(f"world=dist: {{time.time() - t0:.1f}} s, collective calls {{calls}}", flush=True)
+n = det1["embeddings"].shape[0]
+assert n > 5000 and calls == [((n, 192), True, True)]                 # ONE all-gather, of device tensors
+assert np.array_equal(det1["embeddings"], det2["embeddings"]) and np.array_equal(det1["labels"], det2["labels"])
+assert open(wav[:-4] + ".single.rttm").read() == open(wav[:-4] + ".dist.rttm").read() and seg1 == seg2
+assert len(set(det1["labels"].tolist())) >= 2
+# GPU embeddings vs the CPU oracle on every 16th window (full geometry on the host is ~60 segments/s): same clusters
+sub = np.arange(0, n, 16)
+y = audio_io.read_audio(wav, sr=16000, mono=True)[0]
+rows = db.gather_windows(y, det1["window_starts"][sub], 32000)
+sd = synth.make_ecapa_state_dict(speech_encode.SYNTHETIC_SEED)
+e_cpu = encode_batch_ref(sd, rows, torch.float32, EcapaRef(sd, torch.float32))
+e_gpu = det1["embeddings"][sub]
+cd = 1.0 - (e_gpu.astype(np.float64) * e_cpu).sum(1) / (np.linalg.norm(e_gpu, axis=1) * np.linalg.norm(e_cpu, axis=1))
+assert cd.max() < 1e-3, cd.max()
+labs = []
+for e in (e_gpu, e_cpu):
+    K = ops.cosine_affinity(torch.from_numpy(cluster.center(e).astype(np.float32)).cuda()).cpu().numpy()
+    labs.append(cluster.relabel_by_first_appearance(cluster.spectral(K, 8)))
+assert np.array_equal(labs[0], labs[1])
+print(f"subsample of {{len(sub)}} windows: max cosine distance GPU vs CPU oracle {{cd.max():.2e}}, identical cluster labels", flush=True)
+tdist.barrier(); tdist.destroy_process_group()
+print("ok")
+"""
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    print(res.stdout[-1500:])
+    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), (res.stdout[-800:], res.stderr[-2500:])
 
 
 def test_config4_affinity_50k_properties(dev):

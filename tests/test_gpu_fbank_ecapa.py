@@ -174,3 +174,92 @@ def test_ecapa_zero_padding_counts_as_signal(dev):
     got = EmbeddingEngine(sd, dev).embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
     ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
     assert _cos_dist(got, ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["torchaudio", "speechbrain"])
+def test_fbank_windows_in_place_equals_gathered_bitwise(dev, kind):
+    """`sd_fbank_windows_f32` (rows read at starts[b] inside ONE resident signal, zeros past either end) against
+    `sd_fbank_f32` on the gathered, zero-padded [B, n] matrix the reference's callers build on the host
+    [REF anti_stick_diarize.py:82-100, 163-168, 396-430]: the same bits, for overlapping windows, windows that hang
+    over the end of the signal, a window that starts before it, duplicates, and 1 s / 2 s / odd lengths."""
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import fbank_device, fbank_windows_device
+    from speech_diarization_amd.features import FbankPlan
+    plan = FbankPlan(kind)
+    y = synth.synthetic_segments(23, 1, 16000 * 30)[0]
+    yd = torch.from_numpy(y).to(dev)
+    for n, hop in ((32000, 4000), (16000, 1600), (4999, 777)):
+        starts = np.concatenate([np.arange(0, len(y) - n // 2, hop), [len(y) - 5, len(y) - n + 1, 0, 0, -300]]).astype(np.int64)
+        rows = np.zeros((len(starts), n), np.float32)
+        for i, s in enumerate(starts):
+            lo, hi = max(s, 0), min(s + n, len(y))
+            rows[i, lo - s: hi - s] = y[lo:hi]
+        want = fbank_device(torch.from_numpy(rows).to(dev), plan, mean_norm=True)
+        got = fbank_windows_device(yd, torch.from_numpy(starts), n, plan, mean_norm=True)
+        assert got.shape == want.shape and torch.equal(got, want), (kind, n)
+
+
+def test_embed_windows_equals_embed_of_gathered_rows(dev):
+    """The engine entry the pipeline uses (`EmbeddingEngine.embed_windows`): bitwise `embed(gathered)`, full geometry,
+    more windows than one micro-batch, both precisions."""
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    y = synth.synthetic_segments(29, 1, 16000 * 20)[0]
+    starts = np.concatenate([np.arange(0, len(y) - 16000, 4000), [len(y) - 100]]).astype(np.int64)
+    rows = np.zeros((len(starts), 32000), np.float32)
+    for i, s in enumerate(starts):
+        piece = y[s:s + 32000]
+        rows[i, : len(piece)] = piece
+    for precision in ("f32", "f16"):
+        eng = EmbeddingEngine(sd, dev, max_batch=32, precision=precision)
+        a = eng.embed_windows(torch.from_numpy(y).to(dev), torch.from_numpy(starts), 32000)
+        b = eng.embed(torch.from_numpy(rows).to(dev))
+        assert a.shape == (len(starts), 192) and torch.equal(a, b), precision
+    assert eng.embed_windows(torch.from_numpy(y).to(dev), torch.zeros(0, dtype=torch.int64), 32000).shape == (0, 192)
+    with pytest.raises(ValueError, match="too short"):
+        eng.embed_windows(torch.from_numpy(y).to(dev), torch.zeros(1, dtype=torch.int64), 300)
+
+
+@pytest.mark.parametrize("kind", ["torchaudio", "speechbrain"])
+def test_fbank_out_of_range_samples_are_clipped_not_nan(dev, kind):
+    """sd_hip.h: |x| <= 16 is exact; larger samples are clipped to +-16 (un-normalised int16-scale floats used to turn a
+    whole segment into NaNs: the folded sums are scaled by 2^10 before the f16 split).  A NaN sample stays a NaN."""
+    from oracle import fbank_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import fbank_device
+    from speech_diarization_amd.features import FbankPlan
+    plan = FbankPlan(kind)
+    ref_fn = (lambda w: fbank_ref.fbank_batch_ref(w, mean_nor=False)) if kind == "torchaudio" else (lambda w: fbank_ref.speechbrain_fbank_ref(w, mean_norm=False))
+    wav = synth.synthetic_segments(31, 3, 16000, std=0.3)
+    big = wav.copy()
+    big[0] *= 16.0 / np.abs(big[0]).max()              # peak exactly 16: still exact
+    big[1] *= 32768.0                                   # int16-scale floats
+    big[2, 3000] = 1e30
+    got = fbank_device(torch.from_numpy(big).to(dev), plan, mean_norm=False).cpu().numpy()
+    assert np.isfinite(got).all()
+    tol = 2e-4 if kind == "torchaudio" else 1e-3
+    assert np.abs(got[0] - ref_fn(big[:1])[0]).max() < tol
+    clipped = np.clip(big, -16.0, 16.0)
+    assert np.abs(got - ref_fn(clipped)).max() < tol
+    nan = wav.copy(); nan[1, 777] = np.nan
+    g2 = fbank_device(torch.from_numpy(nan).to(dev), plan, mean_norm=False).cpu().numpy()
+    assert np.isnan(g2[1]).any() and np.isfinite(g2[0]).all() and np.isfinite(g2[2]).all()
+
+
+def test_fbank_achieved_error_is_recorded(dev, capsys):
+    """The DFT runs on split f16 (2^-22 relative per product) and the mel product on split bf16 (2^-16): record what that
+    costs against the float64 oracle at the bench shape, next to the tolerance, so that drift is visible in the log."""
+    from oracle import fbank_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import fbank_device
+    from speech_diarization_amd.features import FbankPlan
+    wav = synth.synthetic_segments(41, 24, 32000)
+    out = {}
+    for kind in ("torchaudio", "speechbrain"):
+        got = fbank_device(torch.from_numpy(wav).to(dev), FbankPlan(kind), mean_norm=True).cpu().numpy().astype(np.float64)
+        ref = fbank_ref.fbank_batch_ref(wav) if kind == "torchaudio" else fbank_ref.speechbrain_fbank_ref(wav)
+        out[kind] = float(np.abs(got - ref).max())
+    with capsys.disabled():
+        print(f"\nfbank max abs error vs float64: torchaudio (ln) {out['torchaudio']:.3e}, speechbrain (dB) {out['speechbrain']:.3e}")
+    assert out["torchaudio"] < 2e-4 and out["speechbrain"] < 1e-3

@@ -156,3 +156,17 @@ print("ok")
 """
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stderr[-2000:]
+
+
+def test_diarize_on_gpu_equals_diarize_with_the_cpu_encoder(small_encoder):
+    """`anti_stick_diarize.diarize` end to end [REF anti_stick_diarize.py:493-560]: VAD -> SCD -> embed -> two-stage
+    clustering -> merge -> re-embed -> frame reassignment, HIP path (windows read in place, cosine sites on the device)
+    against the same function with the CPU oracle encoder injected: the same segments, one for one."""
+    from speech_diarization_amd import anti_stick_diarize as asd, synth
+    enc, cpu = small_encoder
+    for seed, seconds, spk in ((5, 40.0, 2), (9, 50.0, 3)):
+        conv = synth.synthetic_conversation(seconds, spk, seed=seed)
+        for kw in (dict(clusterer="ahc", cluster_cos=0.2, scd_thr=3.0), dict(clusterer="hdbscan_two_stage", scd_thr=1.5)):
+            g = asd.diarize(conv.wav, 16000, **kw)
+            c = asd.diarize(conv.wav, 16000, encode=cpu, **kw)
+            assert g and [(s.start, s.end, s.spk) for s in g] == [(s.start, s.end, s.spk) for s in c], (seed, kw)

@@ -79,3 +79,39 @@ def test_der_scorer():
     assert rttm.der(ref, [(0.0, 10.0, "x")]) == pytest.approx(0.5, abs=0.01)   # one speaker confused
     assert rttm.der(ref, [(0.0, 5.0, "x")]) == pytest.approx(0.5, abs=0.01)    # half missed
     assert rttm.der(ref, ref) == 0.0 and rttm.der([], []) == 0.0
+
+
+def test_streaming_ring_is_written_in_place_and_reads_the_last_window():
+    """configs[3] host logic without a GPU: the doubled ring of `StreamingEmbedder` (two hop-sized in-place copies per
+    hop, window start offsets from a table) hands `embed_windows` exactly the last `window_s` of every channel."""
+    import torch
+    from speech_diarization_amd.streaming import StreamingEmbedder
+
+    class StubEngine:
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.seen = []
+
+        def embed_windows(self, signal, starts, n):
+            rows = torch.stack([signal[int(s): int(s) + n] for s in starts])
+            self.seen.append(rows.clone())
+            return rows[:, :192].clone()
+
+    eng = StubEngine()
+    st = StreamingEmbedder(eng, channels=3, window_s=0.5, hop_s=0.125, sr=1600, use_graph=False)   # win 800, hop 200
+    buf_ptr = st._buf.data_ptr()
+    rng = np.random.default_rng(0)
+    feed = rng.standard_normal((3, 200 * 11)).astype(np.float32)
+    for h in range(11):
+        out = st.push(torch.from_numpy(feed[:, h * 200:(h + 1) * 200]))
+        want = np.zeros((3, 800), np.float32)
+        have = feed[:, max(0, (h + 1) * 200 - 800):(h + 1) * 200]
+        want[:, 800 - have.shape[1]:] = have
+        assert np.array_equal(eng.seen[-1].numpy(), want) and np.array_equal(st.ring.numpy(), want)
+        assert out.shape == (3, 192)
+    assert st._buf.data_ptr() == buf_ptr                       # never re-allocated
+    with pytest.raises(ValueError):
+        st.push(torch.zeros(3, 7))
+    with pytest.raises(ValueError):
+        StreamingEmbedder(eng, channels=1, window_s=0.5, hop_s=0.3, sr=1600, use_graph=False)

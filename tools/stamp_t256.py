@@ -7,7 +7,7 @@ inside the kernel (s_memtime cycles per s_memrealtime 100 MHz tick).  Never time
 """
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SD_F16_KERNEL"] = "t256"
+os.environ["SD_EXPERIMENT"] = "1"; os.environ["SD_F16_KERNEL"] = "t256"
 REPS = int(os.environ.get("REPS", "3"))
 import numpy as np, torch
 from speech_diarization_amd import ops, _native
