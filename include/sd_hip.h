@@ -100,7 +100,8 @@ size_t sd_fbank_workspace_bytes(const sd_fbank_plan* plan, int B, int n);
  * mean_norm != 0 subtracts each utterance's per-bin mean over T.
  * Input domain: samples with |x| <= 16 are processed exactly (audio is normalised to [-1, 1] everywhere on this
  * path); larger magnitudes are clipped to +-16 (the split-f16 DFT scales the folded sums by 2^10 and they must
- * stay inside the f16 range), so any finite input gives finite features; a NaN sample gives NaN features. */
+ * stay inside the f16 range), so any finite input gives finite features.  Precondition: finite samples (a NaN or
+ * infinite sample gives unspecified features for ITS row; other rows are unaffected). */
 int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int B, int n,
                  int mean_norm, float* out_dev, int ld_out,
                  void* ws_dev, size_t ws_bytes, sd_stream_t stream);

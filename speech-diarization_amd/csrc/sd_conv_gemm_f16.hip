@@ -387,7 +387,15 @@ __device__ __forceinline__ void sd_direct_epilogue(const sd_conv_args& p, ACC (&
 // lane pair holds into 16 bytes, 16-byte row-contiguous stores (a wave writes whole 128-byte lines), and the column
 // statistics are per-lane sums over the wave's 8 row tiles reduced across 16 lanes with DPP: no LDS round trip, no
 // workgroup barrier.  For the plain epilogue only (ReLU / identity, per-channel bias, no tee): the host selects it.
-template <typename TO, bool DIRECT>
+// SPLIT (the "f32-split16x3" mode, sd_conv1d_cl_split16): both operands arrive as interleaved halves of f32 values,
+// a 128-byte row piece = [hi(k0 .. k0+31) | lo(k0 .. k0+31)] with hi = f16(v), lo = f16(v - hi), and a K step of 32 values
+// takes THREE products, hi.hi + hi.lo + lo.hi (the dropped lo.lo term and the representation error are 2^-22 relative:
+// f32-level accuracy on the f16 matrix cores).  Ring, DMA schedule and fragment traffic are those of the f16 step; the
+// MFMA count per step is 1.5x, so the feed path (the f16 kernel's limit) has 1.5x the time per byte.  Half-slice order
+//   lo(g0).Bhi, hi(g0).Bhi, hi(g0).Blo, lo(g1).Bhi, hi(g1).Bhi, hi(g1).Blo
+// reads every fragment set once, keeps two A sets and both B sets live, and ends on Blo, so that the deferred last
+// half-slice does not collide with the next step's first B read (Bhi).
+template <typename TO, bool DIRECT, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec) {
   constexpr int TBK = 64;
   constexpr int TROW = 128;
@@ -509,6 +517,30 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
     if (nk > 1) issue_a(1);
   }
   int sa = 0, sb = 0;                      // stages of step kt
+  if constexpr (SPLIT) {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (bload || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int sa2 = sa == 0 ? 2 : sa - 1;
+      P3_READ_A(fa0, sa, so1, 0);                                            // lo(g0)
+      P3_READ_B(fb0, sb, so0);                                               // Bhi
+      if (kt > 0) { P3_MMA(1, fa1, fb1); }                                   // deferred hi(g1).Blo of step kt - 1
+      if (bload && kt + 1 < nk) issue_b(sb ^ 1);
+      P3_READ_A(fa1, sa, so0, 0);                                            // hi(g0)
+      P3_MMA(0, fa0, fb0);                                                   // lo(g0).Bhi
+      if (!bload && kt + 2 < nk) issue_a(sa2);
+      P3_READ_B(fb1, sb, so1);                                               // Blo
+      P3_READ_A(fa0, sa, so1, 1);                                            // lo(g1)
+      P3_MMA(0, fa1, fb0);                                                   // hi(g0).Bhi
+      P3_MMA(0, fa1, fb1);                                                   // hi(g0).Blo
+      P3_READ_A(fa1, sa, so0, 1);                                            // hi(g1)
+      P3_MMA(1, fa0, fb0);                                                   // lo(g1).Bhi
+      P3_MMA(1, fa1, fb0);                                                   // hi(g1).Bhi
+      sa = sa == 2 ? 0 : sa + 1;
+      sb ^= 1;
+    }
+  } else {
   for (int kt = 0; kt < nk; ++kt) {
     // ---- barrier(kt): this step's stages have landed, every wave has finished reading the previous step's
     if (bload || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -532,6 +564,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
     P3_MMA(0, fa0, fb1);
     sa = sa == 2 ? 0 : sa + 1;
     sb ^= 1;
+  }
   }
   P3_MMA(1, fa1, fb1);
 #undef P3_READ_A
@@ -577,14 +610,15 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #endif
 }
 
-template <typename TO, bool DIRECT>
+template <typename TO, bool DIRECT, bool SPLIT = false>
 int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
   const long tiles_m = (a->M + TBM - 1) / TBM;
   const long tiles_n = (a->cout + TBN - 1) / TBN;
-  auto kern = conv_gemm_f16_t256_kernel<TO, DIRECT>;
+  auto kern = conv_gemm_f16_t256_kernel<TO, DIRECT, SPLIT>;
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), R3_LDS_BYTES));
   {
-    SdProfScope prof(SD_PROF_CONV_WIDE, stream, 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
+    // work = the algorithmic (f32-equivalent) flops: a split row carries cin / 2 values
+    SdProfScope prof(SD_PROF_CONV_WIDE, stream, (SPLIT ? 1.0 : 2.0) * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), R3_LDS_BYTES, stream, *a, vec);
   }
   SD_CHECK_LAUNCH("conv_gemm_f16_t256_kernel");
@@ -679,4 +713,96 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   if (xa && !ya) return launch<_Float16, float>(a, vec, stream);
   if (!xa && ya) return launch<float, _Float16>(a, vec, stream);
   return launch<float, float>(a, vec, stream);
+}
+
+// ------------------------------------------------------------------------------------------ f32-split16x3
+namespace {
+
+// f32 [M][ldx] columns [col0, col0 + C) -> split-packed rows: value column c at halfs 64 (c / 32) + (c % 32) (hi = f16(v)) and
+// + 32 (lo = f16(v - hi)); columns C .. Cp - 1 (Cp = C rounded up to 32) are zero.  |v| is clamped to the f16 range first
+// (activations of this network are O(1..100); a value beyond 65504 would otherwise become inf - inf = NaN).
+__global__ __launch_bounds__(256) void split16_pack_kernel(const float* __restrict__ x, int ldx, int col0, long M, int C, int Cp,
+                                                           _Float16* __restrict__ out, long ldo_halfs) {
+  const int groups = Cp / 8;                                   // 8 values per thread
+  const long total = M * groups;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / groups;
+    const int c = (int)(i - m * groups) * 8;
+    float v[8];
+    if (c + 8 <= C) {
+      const float* src = x + (size_t)m * ldx + col0 + c;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = c + e < C ? x[(size_t)m * ldx + col0 + c + e] : 0.f;
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = v[e] != v[e] ? v[e] : __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+      hi[e] = (_Float16)w;
+      lo[e] = (_Float16)(w - (float)hi[e]);
+    }
+    _Float16* dst = out + (size_t)m * ldo_halfs + 64 * (c / 32) + (c % 32);
+    *reinterpret_cast<h8*>(dst) = hi;
+    *reinterpret_cast<h8*>(dst + 32) = lo;
+  }
+}
+
+}  // namespace
+
+extern "C" int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int C, void* out, int ldo, sd_stream_t stream) {
+  SD_CHECK_ARG(x && out && M > 0 && C > 0, "sd_split16_pack_f32: null pointer or empty shape");
+  const int Cp = (C + 31) / 32 * 32;
+  SD_CHECK_ARG(ldo >= Cp && ldo % 32 == 0, "sd_split16_pack_f32: ldo=%d must be a multiple of 32 and >= %d", ldo, Cp);
+  SD_CHECK_ARG(col0 >= 0 && col0 + C <= ldx, "sd_split16_pack_f32: slice outside row");
+  SD_CHECK_ARG(sd_aligned16(x) && sd_aligned16(out) && ldx % 4 == 0 && col0 % 4 == 0, "sd_split16_pack_f32: x / out must be 16-byte aligned, ldx and col0 multiples of 4");
+  const long total = (long)M * (Cp / 8);
+  const long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(split16_pack_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, ldx, col0, (long)M, C, Cp, static_cast<_Float16*>(out), (long)ldo * 2);
+  SD_CHECK_LAUNCH("split16_pack_kernel");
+  return SD_OK;
+}
+
+extern "C" int sd_conv1d_cl_split16(const sd_conv_args* a, sd_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_split16: null args");
+  SD_CHECK_ARG(a->x && a->w && a->y, "sd_conv1d_cl_split16: null x/w/y");
+  SD_CHECK_ARG(a->w_dtype == SD_DT_SPLIT16 && a->x_dtype == SD_DT_SPLIT16 && a->y_dtype == SD_DT_F32,
+               "sd_conv1d_cl_split16: x and w must be split-packed (SD_DT_SPLIT16), y f32 (got %d/%d/%d)", a->x_dtype, a->w_dtype, a->y_dtype);
+  SD_CHECK_ARG(a->M > 0 && a->T > 0 && a->M % a->T == 0, "sd_conv1d_cl_split16: M=%d must be a positive multiple of T=%d", a->M, a->T);
+  SD_CHECK_ARG(a->cin > 0 && a->cin_pad >= a->cin && a->cin_pad % 32 == 0, "sd_conv1d_cl_split16: cin=%d cin_pad=%d (a multiple of 32)", a->cin, a->cin_pad);
+  SD_CHECK_ARG(a->cout >= 8 && a->cout % 8 == 0, "sd_conv1d_cl_split16: cout=%d must be a multiple of 8", a->cout);
+  SD_CHECK_ARG(a->taps >= 1 && (a->taps & 1) && a->dil >= 1, "sd_conv1d_cl_split16: taps=%d (odd) dil=%d", a->taps, a->dil);
+  SD_CHECK_ARG((a->taps / 2) * a->dil < a->T, "sd_conv1d_cl_split16: reflect padding %d needs T > pad (T=%d)", (a->taps / 2) * a->dil, a->T);
+  SD_CHECK_ARG(a->lda % 32 == 0 && a->a_col0 % 32 == 0 && a->a_col0 + a->cin_pad <= a->lda,
+               "sd_conv1d_cl_split16: lda=%d a_col0=%d cin_pad=%d (value columns: multiples of 32, slice inside row)", a->lda, a->a_col0, a->cin_pad);
+  SD_CHECK_ARG(a->o_col0 >= 0 && a->o_col0 + a->cout <= a->ldo, "sd_conv1d_cl_split16: output slice outside row");
+  SD_CHECK_ARG(sd_aligned16(a->x) && sd_aligned16(a->w), "sd_conv1d_cl_split16: x and w must be 16-byte aligned");
+  SD_CHECK_ARG(!(a->tee && a->tee_add), "sd_conv1d_cl_split16: the tee_add epilogue is not available on this kernel");
+  if (a->tee)
+    SD_CHECK_ARG(a->tee_lo >= 0 && a->tee_lo < a->tee_hi && a->tee_hi <= a->cout && a->tee_hi - a->tee_lo <= a->ldt,
+                 "sd_conv1d_cl_split16: bad tee range [%d,%d) ldt=%d", a->tee_lo, a->tee_hi, a->ldt);
+  const long tiles = (long)((a->M + TBM - 1) / TBM) * ((a->cout + TBN - 1) / TBN);
+  SD_CHECK_ARG(tiles < (1L << 31), "sd_conv1d_cl_split16: grid too large");
+  int vec = a->cout % 8 == 0 && a->ldo % 8 == 0 && a->o_col0 % 8 == 0 && sd_aligned16(a->y);
+  vec = vec && sd_aligned16(a->bias) && sd_aligned16(a->scale) && sd_aligned16(a->shift);
+  if (a->tee) vec = vec && a->tee_lo % 8 == 0 && a->tee_hi % 8 == 0 && a->ldt % 8 == 0 && sd_aligned16(a->tee);
+  if (a->colstat) {
+    const bool simple = (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg;
+    if (!(vec && simple && a->T >= 128 && a->cout % 256 == 0 && !a->tee))
+      return sd_set_error(SD_ERR_UNSUPPORTED, "sd_conv1d_cl_split16: colstat needs T >= 128, cout %% 256 == 0, relu/identity, per-channel bias, "
+                          "aligned slices and no tee (T=%d cout=%d act=%d/%d)", a->T, a->cout, a->act, a->act2);
+  }
+  // the kernel sees rows of halfs: a value column is two halfs, a K step of 64 halfs is 32 values
+  sd_conv_args k = *a;
+  k.lda = 2 * a->lda; k.a_col0 = 2 * a->a_col0;
+  k.cin = 2 * a->cin_pad; k.cin_pad = 2 * a->cin_pad;
+  k.x_dtype = SD_DT_F16; k.w_dtype = SD_DT_F16;
+  const bool plain = vec && (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg && !a->tee;
+  if (plain) return launch_t256<float, true, true>(&k, vec, stream);
+  return launch_t256<float, false, true>(&k, vec, stream);
 }

@@ -87,9 +87,11 @@ __global__ __launch_bounds__(256) void spin(const h8* __restrict__ ops, int iter
     f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // inline asm: with the builtin, hipcc (ROCm 7.2) rotates the eight accumulators through ~50 v_accvgpr moves per
+    // round of 8 MFMAs, and round 2's "45 cycles per MFMA" was that copy traffic, not the instruction
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) out += acc[i][0] + acc[i][3];
