@@ -51,9 +51,12 @@ typedef void* sd_stream_t; /* hipStream_t */
 #define SD_ERR_WORKSPACE (-3)
 #define SD_ERR_HIP (-4)
 
-#define SD_ABI_VERSION 6
+#define SD_ABI_VERSION 7
 
 int sd_abi_version(void);
+/* sizeof of the structs below as this library was compiled (which: 0 sd_conv_args, 1 sd_layer, 2 sd_se_res2_block,
+ * 3 sd_ecapa_weights; anything else: 0) — lets a binding in another language verify its own layout at load time */
+size_t sd_sizeof(int which);
 const char* sd_last_error(void);
 /* number of HIP devices visible, or negative error */
 int sd_device_count(void);
@@ -125,6 +128,8 @@ int sd_fbank_windows_f32(const sd_fbank_plan* plan, const float* wav_dev, long l
 
 #define SD_DT_F32 0
 #define SD_DT_F16 1
+#define SD_DT_SPLIT16 2 /* f32 VALUES carried as two f16 halves (hi = f16(v), lo = f16(v - hi)), interleaved per 32 values:
+                           value column c sits at halfs 64 (c / 32) + (c % 32) (hi) and + 32 (lo) of its row */
 
 /* Channel-last 1-D convolution as an implicit GEMM on the matrix cores:
  *   y[m, n] = act2( affine( act( bias[n] + sum_{j<taps} sum_{c<cin}
@@ -164,6 +169,19 @@ typedef struct {
 
 int sd_conv1d_cl_f32(const sd_conv_args* args, sd_stream_t stream);
 int sd_conv1d_cl_f16(const sd_conv_args* args, sd_stream_t stream);
+/* "f32-split16x3": the same operator at f32-level accuracy on the f16 matrix cores.  Every f32 operand value is split
+ * v = hi + lo (two f16) and a product is hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16 with f32 accumulation: the
+ * dropped lo.lo term and the representation error are 2^-22 relative per product (exact f32: 2^-24), three f16 MFMAs
+ * instead of one f32 MFMA at 1/16 of their rate.  x: SD_DT_SPLIT16 rows [M][lda] (lda, a_col0, cin, cin_pad count VALUE
+ * columns; lda, a_col0 and cin_pad multiples of 32; made by sd_split16_pack_f32); w: SD_DT_SPLIT16 [cout][taps][cin_pad],
+ * optionally pre-scaled by a power of two 2^s to keep the low halves of small weights out of the f16 subnormals (the
+ * caller then passes bias * 2^s and scale * 2^-s: exact); y: f32.  256x256 tiles (the wide layers: cout >= 256 pays);
+ * epilogue as sd_conv1d_cl_f16's 256x256 kernel (tee without tee_add; colstat needs T >= 128).
+ * Domain: |x| <= 65504 (larger values are clamped when packed). */
+int sd_conv1d_cl_split16(const sd_conv_args* args, sd_stream_t stream);
+/* f32 [M][ldx] columns [col0, col0 + C) -> SD_DT_SPLIT16 rows out [M][ldo] (ldo value columns, a multiple of 32, >= C
+ * rounded up to 32; the padding columns are zero filled); 4 bytes per value in, 4 out. */
+int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int C, void* out, int ldo, sd_stream_t stream);
 /* Kernel-selection knobs (process-wide; for tests and measurements, results stay within f32 rounding).
  * SD_TUNE_SKINNY_TILES: sd_conv1d_cl_f32 launches with fewer 128x128 tiles than `value` run the 32x32
  * split-K kernel (default 128; 0 = always the 128x128 kernel; negative = restore the default). */
@@ -222,6 +240,9 @@ typedef struct {
   const float* shift; /* [cout] eval-BN shift or NULL */
   int cin, cin_pad, cout, taps, dil;
   int w_dtype;        /* SD_DT_F32 or SD_DT_F16 packing of w */
+  /* optional second packing of the same layer for sd_conv1d_cl_split16 (NULL: not packed): SD_DT_SPLIT16
+   * [cout][taps][cin rounded up to 32], scaled by 2^s, with bias * 2^s and scale * 2^-s */
+  const void* w_split; const float* bias_split; const float* scale_split;
 } sd_layer;
 
 #define SD_MAX_RES2 15
@@ -246,6 +267,8 @@ typedef struct {
   int att_channels;   /* 128 */
   int emb_dim;        /* 192 */
   float asp_eps;      /* 1e-12 */
+  int split16;        /* != 0 (with w_dtype SD_DT_F32): layers that carry a w_split packing (the wide ones: stem, tdnn1,
+                         tdnn2, MFA) run on sd_conv1d_cl_split16 — the "f32-split16x3" mode; everything else stays exact f32 */
   sd_layer block0;
   sd_se_res2_block blocks[SD_MAX_BLOCKS];
   sd_layer mfa;

@@ -17,12 +17,12 @@ SD_OK = 0
 SD_PAD_ZERO, SD_PAD_REFLECT = 0, 1
 SD_LOG_LN_EPS, SD_LOG_DB_TOPDB = 0, 1
 SD_ACT_NONE, SD_ACT_RELU, SD_ACT_TANH, SD_ACT_SIGMOID = 0, 1, 2, 3
-SD_DT_F32, SD_DT_F16 = 0, 1
+SD_DT_F32, SD_DT_F16, SD_DT_SPLIT16 = 0, 1, 2
 SD_TUNE_SKINNY_TILES = 1
 SD_TUNE_WIDE_TILES = 2
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
-SD_ABI_VERSION = 6
+SD_ABI_VERSION = 7
 SD_PROF_CONV_GEMM, SD_PROF_FBANK, SD_PROF_CONV_WIDE = 0, 1, 2
 
 
@@ -64,6 +64,7 @@ class sd_layer(C.Structure):
         ("w", C.c_void_p), ("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
         ("cin", C.c_int), ("cin_pad", C.c_int), ("cout", C.c_int), ("taps", C.c_int), ("dil", C.c_int),
         ("w_dtype", C.c_int),
+        ("w_split", C.c_void_p), ("bias_split", C.c_void_p), ("scale_split", C.c_void_p),
     ]
 
 
@@ -81,6 +82,7 @@ class sd_ecapa_weights(C.Structure):
         ("w_dtype", C.c_int), ("n_mels", C.c_int), ("channels", C.c_int), ("n_blocks", C.c_int),
         ("res2_scale", C.c_int), ("mfa_channels", C.c_int), ("att_channels", C.c_int), ("emb_dim", C.c_int),
         ("asp_eps", C.c_float),
+        ("split16", C.c_int),
         ("block0", sd_layer),
         ("blocks", sd_se_res2_block * SD_MAX_BLOCKS),
         ("mfa", sd_layer), ("asp_tdnn_h", sd_layer), ("asp_tdnn_g", sd_layer), ("asp_conv", sd_layer), ("fc", sd_layer),
@@ -95,6 +97,7 @@ _Z = C.c_size_t
 # symbol -> (restype, argtypes); must list every function sd_hip.h declares
 PROTOTYPES = {
     "sd_abi_version": (_I, []),
+    "sd_sizeof": (_Z, [_I]),
     "sd_last_error": (C.c_char_p, []),
     "sd_device_count": (_I, []),
     "sd_profile_enable": (_I, [_I]),
@@ -107,6 +110,8 @@ PROTOTYPES = {
     "sd_fbank_windows_f32": (_I, [_P, _P, C.c_longlong, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_conv1d_cl_f32": (_I, [C.POINTER(sd_conv_args), _P]),
     "sd_conv1d_cl_f16": (_I, [C.POINTER(sd_conv_args), _P]),
+    "sd_conv1d_cl_split16": (_I, [C.POINTER(sd_conv_args), _P]),
+    "sd_split16_pack_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "sd_set_tuning": (_I, [_I, C.c_long]),
     "sd_colstat_floats": (_Z, [_I, _I]),
     "sd_colstat_finish_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
@@ -173,6 +178,9 @@ def load() -> C.CDLL:
             fn.argtypes = args
         if lib.sd_abi_version() != SD_ABI_VERSION:
             raise RuntimeError(f"libsd_hip.so ABI {lib.sd_abi_version()} != binding ABI {SD_ABI_VERSION}; rebuild")
+        for which, st in enumerate((sd_conv_args, sd_layer, sd_se_res2_block, sd_ecapa_weights)):
+            if lib.sd_sizeof(which) != C.sizeof(st):
+                raise RuntimeError(f"{st.__name__}: binding layout is {C.sizeof(st)} bytes, the library's {lib.sd_sizeof(which)}; rebuild")
         _lib = lib
     return _lib
 

@@ -23,6 +23,16 @@ int sd_set_error(int code, const char* fmt, ...) {
 extern "C" const char* sd_last_error(void) { return g_err; }
 extern "C" int sd_abi_version(void) { return SD_ABI_VERSION; }
 
+extern "C" size_t sd_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(sd_conv_args);
+    case 1: return sizeof(sd_layer);
+    case 2: return sizeof(sd_se_res2_block);
+    case 3: return sizeof(sd_ecapa_weights);
+    default: return 0;
+  }
+}
+
 extern "C" int sd_device_count(void) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);

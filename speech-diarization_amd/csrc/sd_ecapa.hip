@@ -33,6 +33,7 @@ struct Carver {
 
 struct Buffers {
   void *x0, *r, *t2, *xcat, *h, *s0, *s1, *a1, *e;   // activation dtype (e = attention logits)
+  void* xs;                                            // split16 mode: the SD_DT_SPLIT16 copy of a wide conv's input
   void* wpk; size_t wpk_bytes;                        // Res2Net chain weights in fragment order (f16 path)
   float *semean, *seh, *gate, *stats, *gbias, *pooled;
   size_t bytes;
@@ -64,6 +65,7 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.pooled = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
   b.wpk_bytes = act_dtype == SD_DT_F16 ? sd_res2net_chain_workspace_bytes(w->res2_scale - 1) : 0;
   b.wpk = c.take(b.wpk_bytes, 1);
+  b.xs = (w->split16 && act_dtype == SD_DT_F32) ? c.take(M * (size_t)((Cm + 31) / 32 * 32), 4) : nullptr;
   b.a1 = b.x0;    // block-0 output is dead once block 1 has consumed it
   b.e = b.xcat;
   b.bytes = c.off;
@@ -126,6 +128,21 @@ int run_conv(const sd_conv_args& a, sd_stream_t stream) {
   return a.w_dtype == SD_DT_F16 ? sd_conv1d_cl_f16(&a, stream) : sd_conv1d_cl_f32(&a, stream);
 }
 
+// A wide layer of the f32 schedule: in split16 mode (and when the layer carries the second packing) its f32 input is
+// re-written as SD_DT_SPLIT16 rows (4 bytes per value in, 4 out) and the conv runs on the f16 matrix cores with three
+// products per value pair; otherwise the exact-f32 kernel.
+int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, sd_stream_t stream) {
+  if (!(split && l.w_split && xs && a.x_dtype == SD_DT_F32 && a.y_dtype == SD_DT_F32 && !(a.tee && a.tee_add) &&
+        !(a.colstat && a.T < 128)))
+    return run_conv(a, stream);
+  const int cp = (l.cin + 31) / 32 * 32;
+  if (int e = sd_split16_pack_f32(static_cast<const float*>(a.x), a.lda, a.a_col0, a.M, l.cin, xs, cp, stream)) return e;
+  a.x = xs; a.lda = cp; a.a_col0 = 0; a.x_dtype = SD_DT_SPLIT16;
+  a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = cp;
+  a.bias = l.bias_split; a.scale = l.scale_split;
+  return sd_conv1d_cl_split16(&a, stream);
+}
+
 #define SD_TRY(expr)            \
   do {                          \
     int e_ = (expr);            \
@@ -147,6 +164,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   const int C = w->channels, Cm = w->mfa_channels, chunk = C / w->res2_scale;
   const int F32 = SD_DT_F32;
   const size_t es = dt == SD_DT_F16 ? 2 : 4;
+  const bool split = w->split16 != 0 && dt == SD_DT_F32;      // "f32-split16x3": wide layers on the f16 matrix cores, f32-level accuracy
 
   static const bool colstat_ok = [] {     // SD_COLSTAT=0: A/B switch for measurements
     const char* e = sd_experiment_env("SD_COLSTAT");
@@ -164,7 +182,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       x = b.t2; xdt = SD_DT_F16;
     }
     sd_conv_args a = conv_of(w->block0, x, xdt, w->n_mels, 0, b.x0, dt, C, 0, M, T, SD_ACT_RELU);
-    SD_TRY(run_conv(a, stream));
+    SD_TRY(run_wide(w->block0, a, split, b.xs, stream));
   }
   const void* xin = b.x0; int ldin = C, colin = 0;
   for (int i = 0; i < w->n_blocks; ++i) {
@@ -182,7 +200,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     {
       sd_conv_args a = conv_of(blk.tdnn1, xin, dt, ldin, colin, b.r, dt, C, 0, M, T, SD_ACT_RELU);
       if (!chain) { a.tee = b.s0; a.ldt = chunk; a.tee_lo = chunk; a.tee_hi = 2 * chunk; }
-      SD_TRY(run_conv(a, stream));
+      SD_TRY(run_wide(blk.tdnn1, a, split, b.xs, stream));
     }
     if (chain) {
       SD_TRY(sd_res2net_chain_f16(b.r, C, B, T, blk.res2, w->res2_scale - 1, b.wpk, b.wpk_bytes, stream));
@@ -202,10 +220,10 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // geometry allows (the Res2Net scratch s0 is dead and holds them), else from a pass over t2
     {
       sd_conv_args a = conv_of(blk.tdnn2, b.r, dt, C, 0, b.t2, dt, C, 0, M, T, SD_ACT_RELU);
-      const bool stat = colstat_ok && T >= 64 && C % 256 == 0 &&
+      const bool stat = colstat_ok && T >= (split ? 128 : 64) && C % 256 == 0 &&
                         sd_colstat_floats(M, C) * sizeof(float) <= (size_t)M * chunk * es;
       if (stat) a.colstat = static_cast<float*>(b.s0);
-      SD_TRY(run_conv(a, stream));
+      SD_TRY(run_wide(blk.tdnn2, a, split, b.xs, stream));
       if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
       else SD_TRY(sd_seg_mean_std_dt(b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
     }
@@ -224,10 +242,10 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   // epilogue (column sums in r, dead since the last block's tdnn2)
   {
     sd_conv_args a = conv_of(w->mfa, b.xcat, dt, Cm, 0, b.h, dt, Cm, 0, M, T, SD_ACT_RELU);
-    const bool stat = colstat_ok && T >= 64 && Cm % 256 == 0 &&
+    const bool stat = colstat_ok && T >= (split ? 128 : 64) && Cm % 256 == 0 &&
                       sd_colstat_floats(M, Cm) * sizeof(float) <= (size_t)M * C * es;
     if (stat) a.colstat = static_cast<float*>(b.r);
-    SD_TRY(run_conv(a, stream));
+    SD_TRY(run_wide(w->mfa, a, split, b.xs, stream));
     if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
     else SD_TRY(sd_seg_mean_std_dt(b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
   }

@@ -48,6 +48,24 @@ def pack_conv_weight(w: np.ndarray, dtype=np.float32) -> np.ndarray:
     return out
 
 
+def pack_conv_weight_split16(w: np.ndarray):
+    """[cout, cin, k] f32 -> (SD_DT_SPLIT16 [cout, k, cin_pad / 32, 64] f16, s): the weights scaled by 2^s (max |w| 2^s in
+    [512, 1024): the low halves of small weights stay clear of the f16 subnormals, nothing overflows), every value split
+    hi = f16(v), lo = f16(v - hi), interleaved per 32 input channels [hi x 32 | lo x 32] (sd_hip.h: SD_DT_SPLIT16)."""
+    cout, cin, k = w.shape
+    cp = _pad_to(cin, 32)
+    wmax = float(np.abs(w).max())
+    s = int(np.floor(np.log2(1024.0 / wmax))) - (1 if wmax * 2.0 ** np.floor(np.log2(1024.0 / wmax)) >= 1024.0 else 0) if wmax > 0 else 0
+    v = np.zeros((cout, k, cp), dtype=np.float32)
+    v[:, :, :cin] = np.transpose(w, (0, 2, 1)) * np.float32(2.0 ** s)          # exact: power of two
+    hi = v.astype(np.float16)
+    lo = (v - hi.astype(np.float32)).astype(np.float16)
+    out = np.empty((cout, k, cp // 32, 64), dtype=np.float16)
+    out[..., :32] = hi.reshape(cout, k, cp // 32, 32)
+    out[..., 32:] = lo.reshape(cout, k, cp // 32, 32)
+    return out, s
+
+
 def bn_affine(sd: dict, prefix: str):
     g, b = _np(sd[f"{prefix}.weight"]), _np(sd[f"{prefix}.bias"])
     rm, rv = _np(sd[f"{prefix}.running_mean"]), _np(sd[f"{prefix}.running_var"])
@@ -60,8 +78,8 @@ class EcapaWeights:
     """ECAPA-TDNN weights packed for the HIP kernels and resident on one device."""
 
     def __init__(self, state_dict: dict, device: torch.device, precision: str = "f32"):
-        if precision not in ("f32", "f16"):
-            raise ValueError(f"precision must be 'f32' or 'f16', got {precision!r}")
+        if precision not in ("f32", "f16", "f32s"):
+            raise ValueError(f"precision must be 'f32', 'f16' or 'f32s' (f32-split16x3), got {precision!r}")
         self.device = device
         self.precision = precision
         self.cfg: EcapaConfig = config_from_state_dict(state_dict)
@@ -72,6 +90,7 @@ class EcapaWeights:
         sd = state_dict
         W = N.sd_ecapa_weights()
         W.w_dtype = N.SD_DT_F16 if precision == "f16" else N.SD_DT_F32
+        W.split16 = 1 if precision == "f32s" else 0
         W.n_mels = cfg.input_size
         W.channels = cfg.channels[0]
         W.n_blocks = cfg.n_blocks
@@ -132,6 +151,14 @@ class EcapaWeights:
         else:
             L.scale, L.shift = None, None
         L.cin, L.cin_pad, L.cout, L.taps, L.dil = cin, packed.shape[2], cout, k, dil
+        # "f32s": the wide frame-level layers (stem, tdnn1, tdnn2, MFA: 86 % of the flops) get a second, split-f16 packing
+        if self.precision == "f32s" and not per_segment and cout >= 1024 and affine is not None and bias is not None:
+            ws, s = pack_conv_weight_split16(w)
+            L.w_split = self._dev(ws, np.float16)
+            L.bias_split = self._dev(bias * np.float32(2.0 ** s))
+            L.scale_split = self._dev(affine[0] * np.float32(2.0 ** -s))
+        else:
+            L.w_split, L.bias_split, L.scale_split = None, None, None
 
 
 class EmbeddingEngine:
@@ -151,6 +178,8 @@ class EmbeddingEngine:
             self.plan = FbankPlan("speechbrain", n_mels=self.weights.cfg.input_size)
         self.dim = self.weights.cfg.lin_neurons
         self.precision = precision
+        # "f32s" = f32-split16x3: the f32 schedule (f32 activations) whose wide layers run three f16 MFMA products per value
+        # pair at f32-level accuracy; a property of the packed weights (sd_ecapa_weights.split16), same entry point
         self._forward = self._lib.sd_ecapa_forward_f16 if precision == "f16" else self._lib.sd_ecapa_forward_f32
         self._ws = None
         self._ws_frozen = False

@@ -90,6 +90,66 @@ def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, T: int, *, cin: int, dil:
     return out
 
 
+def split16_pack(x: torch.Tensor, a_col0: int = 0, cin: int | None = None) -> torch.Tensor:
+    """f32 [M, ld] columns [a_col0, a_col0 + cin) -> SD_DT_SPLIT16 rows as an f16 tensor [M, 2 * cin_pad32]
+    (per 32 values: [hi x 32 | lo x 32], hi = f16(v), lo = f16(v - hi); padding values zero)."""
+    _need_cuda(x)
+    if x.dtype != torch.float32 or x.stride(1) != 1:
+        raise TypeError("x must be f32 with contiguous channels")
+    M = x.shape[0]
+    cin = x.shape[1] - a_col0 if cin is None else cin
+    cp = (cin + 31) // 32 * 32
+    out = torch.empty((M, 2 * cp), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.load().sd_split16_pack_f32(x.data_ptr(), x.stride(0), a_col0, M, cin, out.data_ptr(), cp, _stream(x)), "sd_split16_pack_f32")
+    return out
+
+
+def pack_weight_split16(w: torch.Tensor | np.ndarray, device):
+    """[cout, cin, k] -> (SD_DT_SPLIT16 weights as an f16 tensor [cout, k, cin_pad32 / 32, 64] on `device`, s):
+    scaled by 2^s, hi / lo halves interleaved per 32 input channels (`engine.pack_conv_weight_split16`)."""
+    from .engine import pack_conv_weight_split16
+    w = w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
+    packed, s = pack_conv_weight_split16(w.astype(np.float32))
+    return torch.from_numpy(packed).to(device), s
+
+
+def conv1d_cl_split16(x: torch.Tensor, w_split: torch.Tensor, w_shift: int, T: int, *, cin: int, dil: int = 1, bias=None, act=None,
+                      scale=None, shift=None, a_col0: int = 0, out: torch.Tensor | None = None, o_col0: int = 0,
+                      tee: torch.Tensor | None = None, tee_lo: int = 0, tee_hi: int = 0, colstat: torch.Tensor | None = None) -> torch.Tensor:
+    """The "f32-split16x3" conv: f32 x [M, lda] -> f32 y [M, ldo] at f32-level accuracy on the f16 matrix cores
+    (`sd_split16_pack_f32` + `sd_conv1d_cl_split16`).  `w_split`, `w_shift` from `pack_weight_split16`; bias / scale /
+    shift are the layer's ordinary f32 vectors (the 2^s of the weight scaling is folded in here)."""
+    _need_cuda(x, w_split, bias, scale, shift, out, tee, colstat)
+    lib = N.load()
+    cout, taps, chunks, _ = w_split.shape
+    cp = chunks * 32
+    M = x.shape[0]
+    xs = split16_pack(x, a_col0, cin)
+    if out is None:
+        out = torch.empty((M, cout), dtype=torch.float32, device=x.device)
+    f = float(2.0 ** w_shift)
+    bias_s = None if bias is None else bias * f
+    scale_s = (torch.full((cout,), 1.0 / f, dtype=torch.float32, device=x.device) if scale is None else scale / f)
+    a = N.sd_conv_args()
+    a.x, a.lda, a.a_col0 = xs.data_ptr(), cp, 0
+    a.w, a.w_dtype = w_split.data_ptr(), N.SD_DT_SPLIT16
+    a.x_dtype, a.y_dtype = N.SD_DT_SPLIT16, N.SD_DT_F32
+    a.y, a.ldo, a.o_col0 = out.data_ptr(), out.stride(0), o_col0
+    a.M, a.T = M, T
+    a.cin, a.cin_pad, a.cout, a.taps, a.dil = cin, cp, cout, taps, dil
+    a.bias, a.bias_per_seg = _ptr(bias_s), 0
+    a.act, a.act2 = _ACT[act], _ACT[None]
+    a.scale, a.shift = _ptr(scale_s), _ptr(shift)
+    if tee is not None:
+        a.tee, a.ldt, a.tee_lo, a.tee_hi = tee.data_ptr(), tee.stride(0), tee_lo, tee_hi
+    if colstat is not None:
+        a.colstat = colstat.data_ptr()
+    with torch.cuda.device(x.device):
+        N.check(lib.sd_conv1d_cl_split16(C.byref(a), _stream(x)), "sd_conv1d_cl_split16")
+    return out
+
+
 def res2net_chain_supported(T: int, chunk: int = 128, n: int = 7, taps: int = 3, dil: int = 2) -> bool:
     return bool(N.load().sd_res2net_chain_supported(T, chunk, n, taps, dil))
 

@@ -1,0 +1,153 @@
+"""The "f32-split16x3" mode: f32 VALUES carried as two f16 halves, three f16 MFMA products per value pair, f32
+accumulation — f32-level accuracy on the f16 matrix cores for the wide layers (stem, tdnn1, tdnn2, MFA).
+
+It must pass the exact-f32 path's bars: embeddings within 1e-5 cosine / 1e-3 * max absolute of the float64 oracle at the
+full geometry, identical cluster assignments; per operator the error against float64 is compared with what the exact-f32
+kernel achieves on the same inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos_dist(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+def _ref_conv_cl(x, w, b, T, dil):
+    M, cin = x.shape
+    xt = x.view(M // T, T, cin).transpose(1, 2)
+    pad = dil * (w.shape[2] - 1) // 2
+    if pad:
+        xt = F.pad(xt, (pad, pad), mode="reflect")
+    return F.conv1d(xt, w, b, dilation=dil).transpose(1, 2).reshape(M, -1)
+
+
+def test_split16_pack_layout_and_accuracy(dev):
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(37, 200, generator=g) * torch.logspace(-6, 3, 200)[None, :]      # magnitudes 1e-6 .. 1e3
+    x[3, 10] = 1e6                                                                      # beyond the f16 range: clamped
+    x[5, 11] = 0.0
+    p = ops.split16_pack(x.to(dev), a_col0=8, cin=150).cpu()                         # 150 -> 160 value columns
+    assert p.shape == (37, 320) and p.dtype == torch.float16
+    v = p.view(37, 5, 2, 32)
+    hi, lo = v[:, :, 0, :].reshape(37, 160).double(), v[:, :, 1, :].reshape(37, 160).double()
+    want = x[:, 8:158].double().clamp(-65504.0, 65504.0)
+    assert torch.equal(hi[:, :150], want.float().half().double())                     # hi = f16(v)
+    rec = hi + lo
+    assert (rec[:, 150:] == 0).all()
+    # v = hi + lo to 2^-22 relative, or 2^-25 absolute where lo is an f16 subnormal
+    assert ((rec[:, :150] - want).abs() <= np.maximum(2.0 ** -22 * want.abs(), 2.0 ** -25)).all()
+
+
+@pytest.mark.parametrize("B,T,cin,cout,k,dil", [
+    (3, 201, 1024, 1024, 1, 1),      # tdnn1 / tdnn2
+    (2, 201, 80, 1024, 5, 1),        # stem: k = 5 reflect gather, cin padded 80 -> 96
+    (2, 150, 3072, 3072, 1, 1),      # MFA, tiles spanning two segments
+    (5, 101, 256, 1280, 1, 1),       # 1 s windows, cout not a multiple of the tile
+    (1, 40, 96, 256, 3, 2),          # one partial tile, dilated
+])
+def test_conv1d_cl_split16_is_as_accurate_as_exact_f32(dev, B, T, cin, cout, k, dil):
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(B * 131 + T + cout)
+    x = torch.randn(B * T, cin, generator=g) * 3.0
+    x[:, ::7] *= 1e-3                                       # small and large channels side by side
+    w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    ref = torch.relu(_ref_conv_cl(x.double(), w.double(), b.double(), T, dil)) * scale.double() + shift.double()
+    ws, s = ops.pack_weight_split16(w, dev)
+    got = ops.conv1d_cl_split16(x.to(dev), ws, s, T, cin=cin, dil=dil, bias=b.to(dev), act="relu", scale=scale.to(dev), shift=shift.to(dev))
+    f32 = ops.conv1d_cl(x.to(dev), ops.pack_weight(w, dev), T, cin=cin, dil=dil, bias=b.to(dev), act="relu", scale=scale.to(dev), shift=shift.to(dev))
+    torch.cuda.synchronize()
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    e_split = (got.cpu().double() - ref).abs().max().item()
+    e_f32 = (f32.cpu().double() - ref).abs().max().item()
+    top = ref.abs().max().item()
+    print(f"\n[{B}x{T} {cin}->{cout} k{k}] max abs error vs float64: split16x3 {e_split:.3e}, exact f32 {e_f32:.3e} (output max {top:.2f})")
+    assert e_split < 2e-6 * max(1.0, top)                  # f32-level: the exact-f32 kernel's own bar
+    assert e_split < 8.0 * e_f32 + 1e-7 * top
+
+
+def test_conv1d_cl_split16_tee_and_colstat(dev):
+    """The two epilogues the wide layers use: tdnn1's store-only tee (LDS-staged epilogue) and tdnn2 / MFA's column
+    statistics (register epilogue), against the exact-f32 kernel's outputs."""
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(33)
+    B, T, cin, cout, chunk = 3, 201, 256, 1024, 128
+    x = torch.randn(B * T, cin, generator=g)
+    w = torch.randn(cout, cin, 1, generator=g) / 16
+    b, scale, shift = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    ws, s = ops.pack_weight_split16(w, dev)
+    kw = dict(cin=cin, bias=b.to(dev), act="relu", scale=scale.to(dev), shift=shift.to(dev))
+    tee = torch.zeros(B * T, chunk, device=dev)
+    y = ops.conv1d_cl_split16(x.to(dev), ws, s, T, tee=tee, tee_lo=chunk, tee_hi=2 * chunk, **kw)
+    y32 = ops.conv1d_cl(x.to(dev), ops.pack_weight(w, dev), T, **kw)
+    assert (y - y32).abs().max() < 2e-6 * y32.abs().max() and torch.equal(tee, y[:, chunk:2 * chunk])
+    cs = torch.zeros(ops.colstat_floats(B * T, cout), device=dev)
+    y2 = ops.conv1d_cl_split16(x.to(dev), ws, s, T, colstat=cs, **kw)
+    assert torch.equal(y2, y)
+    st = ops.colstat_finish(cs, y2, B, T, pivot=shift.to(dev), want_std=True)
+    yd = y2.double().view(B, T, cout)
+    mean, std = yd.mean(1), yd.var(1, unbiased=False).clamp_min(1e-12).sqrt()
+    assert (st[:, :cout].double() - mean).abs().max() < 1e-5 and (st[:, cout:].double() - std).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("B,n", [(4, 32000), (5, 16000), (2, 100000), (3, 9600)])
+def test_ecapa_split16_full_geometry_matches_oracle(dev, B, n):
+    """The exact-f32 path's full-geometry test (tests/test_gpu_fbank_ecapa.py) with the SAME bars, on the split16x3 engine;
+    also reports how far it sits from the exact-f32 engine."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    wav = synth.synthetic_segments(0, B, n)
+    got = EmbeddingEngine(sd, dev, precision="f32s").embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    f32 = EmbeddingEngine(sd, dev, precision="f32").embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
+    cd, cd32 = _cos_dist(got, ref), _cos_dist(f32, ref)
+    print(f"\nsplit16x3 vs float64: cos-dist {cd.max():.2e}, abs {np.abs(got - ref).max() / np.abs(ref).max():.2e} of max; "
+          f"exact f32 vs float64: {cd32.max():.2e}, {np.abs(f32 - ref).max() / np.abs(ref).max():.2e}")
+    assert cd.max() < 1e-5, cd
+    assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max()
+    assert not np.array_equal(got, f32)                      # it IS another kernel
+
+
+def test_split16_identical_clusters_and_properties_at_full_size(dev):
+    """north_star's 'identical cluster assignments' for the split16x3 engine (vs the exact-f32 engine and the CPU oracle,
+    C = 1024), and the configs[1] batch (5000 segments through the 256x256 kernel at full occupancy): finite, run-to-run
+    bitwise, within 1e-6 cosine of the exact-f32 engine."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import cluster, ops, synth
+    from speech_diarization_amd.diarization_baseline import gather_windows, speech_windows
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    conv = synth.synthetic_conversation(30.0, 3, seed=2)
+    starts, _, _ = speech_windows([(s, e) for s, e, _ in conv.turns], len(conv.wav), 16000, 2.0, 0.5)
+    wav = gather_windows(conv.wav, starts, 32000)
+    eng = EmbeddingEngine(sd, dev, max_batch=2500, precision="f32s")
+    embs = [eng.embed(torch.from_numpy(wav).to(dev)).cpu().numpy(),
+            EmbeddingEngine(sd, dev, precision="f32").embed(torch.from_numpy(wav).to(dev)).cpu().numpy(),
+            pipeline_ref.encode_batch_ref(sd, wav, torch.float32)]
+    labels = []
+    for emb in embs:
+        K = ops.cosine_affinity(torch.from_numpy(cluster.center(emb).astype(np.float32)).to(dev)).cpu().numpy()
+        labels.append((cluster.relabel_by_first_appearance(cluster.spectral(K, 3)), cluster.relabel_by_first_appearance(cluster.ahc_cosine(K, 0.3))))
+    for lab in labels[1:]:
+        assert np.array_equal(lab[0], labels[0][0]) and np.array_equal(lab[1], labels[0][1])
+    assert _cos_dist(embs[0], embs[2]).max() < 1e-5
+    g = torch.Generator(device=dev).manual_seed(11)
+    big = (torch.randn((5000, 32000), generator=g, device=dev) * 0.1).clamp_(-1.0, 1.0)
+    a = eng.embed(big)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, eng.embed(big))
+    del eng
+    torch.cuda.empty_cache()
+    b = EmbeddingEngine(sd, dev, max_batch=2500, precision="f32").embed(big)
+    cd = 1.0 - torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)
+    print(f"\n5000 segments: split16x3 vs exact f32 max cosine distance {float(cd.max()):.2e}")
+    assert float(cd.max()) < 1e-6
