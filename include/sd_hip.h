@@ -179,9 +179,10 @@ int sd_conv1d_cl_f16(const sd_conv_args* args, sd_stream_t stream);
  * epilogue as sd_conv1d_cl_f16's 256x256 kernel (tee without tee_add; colstat needs T >= 128).
  * Domain: |x| <= 65504 (larger values are clamped when packed). */
 int sd_conv1d_cl_split16(const sd_conv_args* args, sd_stream_t stream);
-/* f32 [M][ldx] columns [col0, col0 + C) -> SD_DT_SPLIT16 rows out [M][ldo] (ldo value columns, a multiple of 32, >= C
- * rounded up to 32; the padding columns are zero filled); 4 bytes per value in, 4 out. */
-int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int C, void* out, int ldo, sd_stream_t stream);
+/* f32 [M][ldx] columns [col0, col0 + C), each multiplied by `mul` (a power of two: exact; 1 for activations) ->
+ * SD_DT_SPLIT16 rows out [M][ldo] (ldo value columns, a multiple of 32, >= C rounded up to 32; the padding columns
+ * are zero filled); 4 bytes per value in, 4 out. */
+int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int C, float mul, void* out, int ldo, sd_stream_t stream);
 /* Kernel-selection knobs (process-wide; for tests and measurements, results stay within f32 rounding).
  * SD_TUNE_SKINNY_TILES: sd_conv1d_cl_f32 launches with fewer 128x128 tiles than `value` run the 32x32
  * split-K kernel (default 128; 0 = always the 128x128 kernel; negative = restore the default). */

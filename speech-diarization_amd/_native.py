@@ -111,7 +111,7 @@ PROTOTYPES = {
     "sd_conv1d_cl_f32": (_I, [C.POINTER(sd_conv_args), _P]),
     "sd_conv1d_cl_f16": (_I, [C.POINTER(sd_conv_args), _P]),
     "sd_conv1d_cl_split16": (_I, [C.POINTER(sd_conv_args), _P]),
-    "sd_split16_pack_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    "sd_split16_pack_f32": (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _P]),
     "sd_set_tuning": (_I, [_I, C.c_long]),
     "sd_colstat_floats": (_Z, [_I, _I]),
     "sd_colstat_finish_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

@@ -160,19 +160,28 @@ extern "C" int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row
   return sd_conv1d_cl_f32(&a, stream);
 }
 
-// The same matrix at the f16 matrix-core rate with f32-level accuracy (BASELINE configs[4]: the 50k x 50k
-// affinity): normalised rows are split  x = hi + lo  into two f16 operand matrices (sd_pool.hip,
-// split16_rows_kernel) and  hi.hi + hi.lo + lo.hi  is ONE f16 GEMM over K = 3 * D with f32 accumulation,
-// run by the conv operator's 256x256 LDS-DMA kernel; the result is then bound by writing 4 N^2 bytes.
-static int pad64(int d) { return (d + 63) & ~63; }
-
+// The same matrix at the f16 matrix-core rate with f32-level accuracy (BASELINE configs[4]: the 50k x 50k affinity): the
+// normalised rows, scaled by 2^4 (low halves of typical entries ~0.07 stay clear of the f16 subnormals), are packed once as
+// SD_DT_SPLIT16 (hi = f16(v), lo = f16(v - hi) per 32 values) and the product is the three-MFMA form hi.hi + hi.lo + lo.hi of
+// sd_conv1d_cl_split16 with the SAME packed matrix on both sides; the epilogue takes the 2^-8 back.  The whole matrix is
+// computed on and above the diagonal only and every off-diagonal 256 x 256 tile is stored twice, as is and transposed through
+// LDS (whole 512-byte runs); what is left is writing 4 N^2 bytes.
+static int pad32s(int d) { return (d + 31) & ~31; }
 
 extern "C" size_t sd_cosine_split16_workspace_bytes(int N, int D) {
   if (N <= 0 || D <= 0) return 0;
   const size_t f32 = ((size_t)N * pad32(D) * sizeof(float) + 255) & ~(size_t)255;
-  const size_t h = ((size_t)N * 3 * pad64(D) * 2 + 255) & ~(size_t)255;
-  return f32 + 2 * h;
+  const size_t h = ((size_t)N * 2 * pad32s(D) * 2 + 255) & ~(size_t)255;
+  const size_t sc = ((size_t)N * sizeof(float) + 255) & ~(size_t)255;
+  return f32 + h + sc;
 }
+
+namespace {
+__global__ void fill_f32_kernel(float* p, int n, float v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+}  // namespace
 
 extern "C" int sd_cosine_affinity_rows_split16(const float* x, int N, int D, int row_lo, int row_hi, float* out, int ldo,
                                                void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
@@ -184,23 +193,29 @@ extern "C" int sd_cosine_affinity_rows_split16(const float* x, int N, int D, int
   if (ws_bytes < sd_cosine_split16_workspace_bytes(N, D))
     return sd_set_error(SD_ERR_WORKSPACE, "sd_cosine_affinity_rows_split16: workspace %zu < %zu bytes", ws_bytes,
                         sd_cosine_split16_workspace_bytes(N, D));
-  const int Dp = pad32(D), Dk = pad64(D);
+  const int Dp = pad32(D), Ds = pad32s(D);
   char* ws = static_cast<char*>(ws_dev);
   float* xn = reinterpret_cast<float*>(ws);
   const size_t f32 = ((size_t)N * Dp * sizeof(float) + 255) & ~(size_t)255;
-  const size_t h = ((size_t)N * 3 * Dk * 2 + 255) & ~(size_t)255;
-  void* A = ws + f32;
-  void* B = ws + f32 + h;
+  const size_t h = ((size_t)N * 2 * Ds * 2 + 255) & ~(size_t)255;
+  char* xs = ws + f32;                                          // SD_DT_SPLIT16 [N][Ds]
+  float* sc = reinterpret_cast<float*>(ws + f32 + h);           // [N] = 2^-8
   int e = sd_l2norm_rows_f32(x, D, N, D, 0.f, 1, xn, Dp, stream);
   if (e != SD_OK) return e;
-  e = sd_split16_rows(xn, Dp, N, D, Dk, A, B, stream);
+  e = sd_split16_pack_f32(xn, Dp, 0, N, D, 16.f, xs, Ds, stream);
   if (e != SD_OK) return e;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), sc, N, 1.0f / 256.0f);
+  SD_CHECK_LAUNCH("fill_f32_kernel");
   sd_conv_args a = {};
-  a.x = static_cast<char*>(A) + (size_t)row_lo * 3 * Dk * 2; a.lda = 3 * Dk; a.a_col0 = 0; a.x_dtype = SD_DT_F16;
-  a.w = B; a.w_dtype = SD_DT_F16;
+  a.x = xs + (size_t)row_lo * 2 * Ds * 2; a.lda = Ds; a.a_col0 = 0; a.x_dtype = SD_DT_SPLIT16;
+  a.w = xs; a.w_dtype = SD_DT_SPLIT16;
   a.y = out; a.ldo = ldo; a.o_col0 = 0; a.y_dtype = SD_DT_F32;
   a.M = row_hi - row_lo; a.T = 1;
-  a.cin = 3 * Dk; a.cin_pad = 3 * Dk; a.cout = N; a.taps = 1; a.dil = 1;
+  a.cin = D; a.cin_pad = Ds; a.cout = N; a.taps = 1; a.dil = 1;
   a.act = SD_ACT_NONE; a.act2 = SD_ACT_NONE;
-  return sd_conv1d_cl_f16(&a, stream);
+  a.scale = sc;
+  static const bool sym = [] { const char* e = sd_experiment_env("SD_AFFINITY_SYM"); return !e || atoi(e) != 0; }();
+  const bool aligned = N % 8 == 0 && ldo % 8 == 0 && sd_aligned16(out);      // the register epilogue's 16-byte stores
+  if (sym && aligned && row_lo == 0 && row_hi == N) return sd_conv1d_cl_split16_symmetric(&a, stream);
+  return sd_conv1d_cl_split16(&a, stream);
 }

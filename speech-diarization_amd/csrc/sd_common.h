@@ -10,10 +10,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int sd_set_error(int code, const char* fmt, ...);
-// library-internal (sd_pool.hip): L2-normalised f32 rows -> the two f16 operand matrices of the split-precision affinity
+// library-internal entry points
 int sd_conv1d_cl_f32_symmetric(const sd_conv_args* a, sd_stream_t stream);   // sd_conv_gemm.hip: x == w, upper triangle + mirror
+int sd_conv1d_cl_split16_symmetric(const sd_conv_args* a, sd_stream_t stream); // sd_conv_gemm_f16.hip: x == w, upper triangle + mirror
 int sd_cast_f32_f16(const float* x, long n, void* y, sd_stream_t stream);           // sd_pool.hip
-int sd_split16_rows(const float* x, int ldx, int N, int D, int Dk, void* A, void* B, sd_stream_t stream);
 
 #define SD_CHECK_ARG(cond, ...)                            \
   do {                                                     \

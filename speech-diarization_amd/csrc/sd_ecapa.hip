@@ -136,7 +136,7 @@ int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, sd_stream_
         !(a.colstat && a.T < 128)))
     return run_conv(a, stream);
   const int cp = (l.cin + 31) / 32 * 32;
-  if (int e = sd_split16_pack_f32(static_cast<const float*>(a.x), a.lda, a.a_col0, a.M, l.cin, xs, cp, stream)) return e;
+  if (int e = sd_split16_pack_f32(static_cast<const float*>(a.x), a.lda, a.a_col0, a.M, l.cin, 1.f, xs, cp, stream)) return e;
   a.x = xs; a.lda = cp; a.a_col0 = 0; a.x_dtype = SD_DT_SPLIT16;
   a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = cp;
   a.bias = l.bias_split; a.scale = l.scale_split;

@@ -343,23 +343,6 @@ __global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __rest
 }
 
 // x (f32, already L2-normalised, row stride ldx) -> two f16 operand matrices [N][3 Dk] for the
-// split-precision affinity: x = hi + lo with hi = f16(x), lo = f16(x - hi);  x.y ~= hi.hi + hi.lo + lo.hi
-// (the dropped lo.lo term is 2^-22 relative), so  A = [hi | hi | lo],  B = [hi | lo | hi]  and one f16 GEMM
-// over K = 3 Dk with f32 accumulation gives the f32-accurate product at the f16 MFMA rate.
-__global__ __launch_bounds__(256) void split16_rows_kernel(const float* __restrict__ x, int ldx, int N, int D, int Dk,
-                                                           _Float16* __restrict__ A, _Float16* __restrict__ B) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)N * Dk) return;
-  const int row = (int)(i / Dk), k = (int)(i % Dk);
-  const float v = k < D ? x[(size_t)row * ldx + k] : 0.f;
-  const _Float16 hi = (_Float16)v;
-  const _Float16 lo = (_Float16)(v - (float)hi);
-  _Float16* a = A + (size_t)row * 3 * Dk + k;
-  _Float16* b = B + (size_t)row * 3 * Dk + k;
-  a[0] = hi; a[Dk] = hi; a[2 * Dk] = lo;
-  b[0] = hi; b[Dk] = lo; b[2 * Dk] = hi;
-}
-
 }  // namespace
 
 // f32 -> f16 (round to nearest even), n % 8 == 0 elements, both 16-byte aligned: the features in front of the f16 stem
@@ -437,15 +420,6 @@ extern "C" int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate
 extern "C" int sd_se_scale_residual_f32(const float* x, int ldx, const float* gate, const float* res, int ldr, int r_col0,
                                         float* y, int ldy, int y_col0, int B, int T, int C, sd_stream_t stream) {
   return sd_se_scale_residual_dt(x, ldx, gate, res, ldr, r_col0, y, ldy, y_col0, B, T, C, SD_DT_F32, stream);
-}
-
-int sd_split16_rows(const float* x, int ldx, int N, int D, int Dk, void* A, void* B, sd_stream_t stream) {
-  SD_CHECK_ARG(x && A && B && N > 0 && D > 0 && Dk >= D && ldx >= D, "sd_split16_rows: bad arguments");
-  const long n = (long)N * Dk;
-  hipLaunchKernelGGL(split16_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, N, D, Dk,
-                     static_cast<_Float16*>(A), static_cast<_Float16*>(B));
-  SD_CHECK_LAUNCH("split16_rows_kernel");
-  return SD_OK;
 }
 
 extern "C" size_t sd_colstat_floats(int M, int cout) {

@@ -90,7 +90,7 @@ def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, T: int, *, cin: int, dil:
     return out
 
 
-def split16_pack(x: torch.Tensor, a_col0: int = 0, cin: int | None = None) -> torch.Tensor:
+def split16_pack(x: torch.Tensor, a_col0: int = 0, cin: int | None = None, mul: float = 1.0) -> torch.Tensor:
     """f32 [M, ld] columns [a_col0, a_col0 + cin) -> SD_DT_SPLIT16 rows as an f16 tensor [M, 2 * cin_pad32]
     (per 32 values: [hi x 32 | lo x 32], hi = f16(v), lo = f16(v - hi); padding values zero)."""
     _need_cuda(x)
@@ -101,7 +101,7 @@ def split16_pack(x: torch.Tensor, a_col0: int = 0, cin: int | None = None) -> to
     cp = (cin + 31) // 32 * 32
     out = torch.empty((M, 2 * cp), dtype=torch.float16, device=x.device)
     with torch.cuda.device(x.device):
-        N.check(N.load().sd_split16_pack_f32(x.data_ptr(), x.stride(0), a_col0, M, cin, out.data_ptr(), cp, _stream(x)), "sd_split16_pack_f32")
+        N.check(N.load().sd_split16_pack_f32(x.data_ptr(), x.stride(0), a_col0, M, cin, C.c_float(mul), out.data_ptr(), cp, _stream(x)), "sd_split16_pack_f32")
     return out
 
 

@@ -78,6 +78,35 @@ def micro_batch_sweep(state_dict, dev, precision):
     return out
 
 
+def reassignment_windows(state_dict, dev, precision="f32"):
+    """the frame-level reassignment workload of one hour of audio [REF anti_stick_diarize.py:396-430]: 1 s
+    windows every 0.1 s = 36 k windows per hour, embedded (a) in place from the ONE resident signal (`embed_windows`:
+    230 MB uploaded once) and (b) the round-2 way: a torch advanced-index gather that materialises [36 k, 16 000] f32
+    (2.3 GB written and re-read) and `embed`.  Also the H2D volumes of a 1 h meeting at 2 s / 0.25 s windows."""
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sr, win, step = 16000, 16000, 1600
+    y = (torch.randn(3600 * sr, device=dev) * 0.1).clamp_(-1, 1)
+    starts = torch.arange(0, y.numel() - win, step, device=dev, dtype=torch.int64)
+    eng = EmbeddingEngine(state_dict, dev, max_batch=4096, precision=precision)
+    res = {"precision": precision, "windows": int(starts.numel())}
+    ar = torch.arange(win, device=dev)
+    def in_place():
+        return [eng.embed_windows(y, starts[lo:lo + 4096], win) for lo in range(0, starts.numel(), 4096)]
+    def gathered():
+        return [eng.embed(y[starts[lo:lo + 4096, None] + ar[None, :]]) for lo in range(0, starts.numel(), 4096)]
+    for name, fn in (("in_place", in_place), ("gathered", gathered)):
+        fn(); torch.cuda.synchronize()
+        best = float("inf")
+        for _ in range(2):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        res[name + "_windows_per_s"] = starts.numel() / best
+        res[name + "_s_per_hour_of_audio"] = best
+    n_win_2s = (3600 * sr - 32000) // 4000 + 1
+    res["h2d_bytes_1h_meeting"] = {"signal_once": 3600 * sr * 4, "gathered_2s_windows_every_0.25s": n_win_2s * 32000 * 4}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--hops", type=int, default=200)
@@ -97,7 +126,8 @@ def main():
         torch.cuda.synchronize()
         t.append(time.perf_counter() - t0)
     dt = min(t)
-    out["micro_batch_sweep"] = {p: micro_batch_sweep(sd, dev, p) for p in ("f32", "f16")}
+    out["micro_batch_sweep"] = {p: micro_batch_sweep(sd, dev, p) for p in ("f32", "f16", "f32s")}
+    out["reassignment_windows_1h"] = [reassignment_windows(sd, dev, p) for p in ("f32", "f32s", "f16")]
     out["host_api_numpy_in_out_f32"] = [host_api_rate(b, n) for b, n in ((32, 32000), (128, 32000), (128, 16000))]
     out["affinity_50k"] = {"ms": dt * 1e3, "tflops": 384.0 * 50000 ** 2 / dt / 1e12, "write_tb_s": 4.0 * 50000 ** 2 / dt / 1e12}
     ops.cosine_affinity(x, out=K, split16=True)
