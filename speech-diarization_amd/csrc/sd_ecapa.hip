@@ -33,7 +33,8 @@ struct Carver {
 
 struct Buffers {
   void *x0, *r, *t2, *xcat, *h, *s0, *s1, *a1, *e;   // activation dtype (e = attention logits)
-  void* xs;                                            // split16 mode: the SD_DT_SPLIT16 copy of a wide conv's input
+  void* xs;                                            // split16 mode: the SD_DT_SPLIT16 copy of a wide conv's input (pack scratch)
+  void* xcs;                                           // split16 mode: SD_DT_SPLIT16 twin of xcat, written by the SE scale + residual kernel
   void* wpk; size_t wpk_bytes;                        // Res2Net chain weights in fragment order (f16 path)
   float *semean, *seh, *gate, *stats, *gbias, *pooled;
   size_t bytes;
@@ -66,6 +67,7 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.wpk_bytes = act_dtype == SD_DT_F16 ? sd_res2net_chain_workspace_bytes(w->res2_scale - 1) : 0;
   b.wpk = c.take(b.wpk_bytes, 1);
   b.xs = (w->split16 && act_dtype == SD_DT_F32) ? c.take(M * (size_t)((Cm + 31) / 32 * 32), 4) : nullptr;
+  b.xcs = (w->split16 && act_dtype == SD_DT_F32 && Cm % 32 == 0 && C % 32 == 0) ? c.take(M * (size_t)Cm, 4) : nullptr;
   b.a1 = b.x0;    // block-0 output is dead once block 1 has consumed it
   b.e = b.xcat;
   b.bytes = c.off;
@@ -131,13 +133,18 @@ int run_conv(const sd_conv_args& a, sd_stream_t stream) {
 // A wide layer of the f32 schedule: in split16 mode (and when the layer carries the second packing) its f32 input is
 // re-written as SD_DT_SPLIT16 rows (4 bytes per value in, 4 out) and the conv runs on the f16 matrix cores with three
 // products per value pair; otherwise the exact-f32 kernel.
-int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, sd_stream_t stream) {
+// twin / twin_ld: an SD_DT_SPLIT16 copy of a.x that already exists (same value columns a.a_col0 .. of rows of twin_ld value columns)
+int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, sd_stream_t stream, const void* twin = nullptr, int twin_ld = 0) {
   if (!(split && l.w_split && xs && a.x_dtype == SD_DT_F32 && a.y_dtype == SD_DT_F32 && !(a.tee && a.tee_add) &&
         !(a.colstat && a.T < 128)))
     return run_conv(a, stream);
   const int cp = (l.cin + 31) / 32 * 32;
-  if (int e = sd_split16_pack_f32(static_cast<const float*>(a.x), a.lda, a.a_col0, a.M, l.cin, 1.f, xs, cp, stream)) return e;
-  a.x = xs; a.lda = cp; a.a_col0 = 0; a.x_dtype = SD_DT_SPLIT16;
+  if (twin && l.cin % 32 == 0 && a.a_col0 % 32 == 0) {
+    a.x = twin; a.lda = twin_ld; a.x_dtype = SD_DT_SPLIT16;            // (a_col0 stays: the twin has the layout of the f32 buffer)
+  } else {
+    if (int e = sd_split16_pack_f32(static_cast<const float*>(a.x), a.lda, a.a_col0, a.M, l.cin, 1.f, xs, cp, stream)) return e;
+    a.x = xs; a.lda = cp; a.a_col0 = 0; a.x_dtype = SD_DT_SPLIT16;
+  }
   a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = cp;
   a.bias = l.bias_split; a.scale = l.scale_split;
   return sd_conv1d_cl_split16(&a, stream);
@@ -200,7 +207,8 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     {
       sd_conv_args a = conv_of(blk.tdnn1, xin, dt, ldin, colin, b.r, dt, C, 0, M, T, SD_ACT_RELU);
       if (!chain) { a.tee = b.s0; a.ldt = chunk; a.tee_lo = chunk; a.tee_hi = 2 * chunk; }
-      SD_TRY(run_wide(blk.tdnn1, a, split, b.xs, stream));
+      // (blocks 2..: the input is a slice of xcat, whose split twin the previous block's SE kernel has written)
+      SD_TRY(run_wide(blk.tdnn1, a, split, b.xs, stream, (i > 0 && xin == b.xcat) ? b.xcs : nullptr, Cm));
     }
     if (chain) {
       SD_TRY(sd_res2net_chain_f16(b.r, C, B, T, blk.res2, w->res2_scale - 1, b.wpk, b.wpk_bytes, stream));
@@ -235,7 +243,8 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       SD_TRY(run_conv(a2, stream));
     }
     // gate * t2 + shortcut -> slice i of the MFA input
-    SD_TRY(sd_se_scale_residual_dt(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, dt, stream));
+    SD_TRY(sd_se_scale_residual_split(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, dt,
+                                      split ? b.xcs : nullptr, Cm, i * C, stream));
     xin = b.xcat; ldin = Cm; colin = i * C;
   }
   // multi-layer feature aggregation; the global mean / std of attentive pooling likewise from the
@@ -245,7 +254,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     const bool stat = colstat_ok && T >= (split ? 128 : 64) && Cm % 256 == 0 &&
                       sd_colstat_floats(M, Cm) * sizeof(float) <= (size_t)M * C * es;
     if (stat) a.colstat = static_cast<float*>(b.r);
-    SD_TRY(run_wide(w->mfa, a, split, b.xs, stream));
+    SD_TRY(run_wide(w->mfa, a, split, b.xs, stream, b.xcs, Cm));
     if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
     else SD_TRY(sd_seg_mean_std_dt(b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
   }

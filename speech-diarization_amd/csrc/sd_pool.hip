@@ -94,11 +94,14 @@ __global__ __launch_bounds__(256) void seg_mean_std_kernel(const T* x, int ld, i
 // y = x * gate[segment] + res, 16 bytes per lane, no 64-bit index arithmetic: a workgroup walks whole
 // rows (grid-stride over row groups), a thread keeps its channel group for all of them, the
 // segment index costs one 32-bit division per row.
+// ys (f32 only, may be null): a second, SD_DT_SPLIT16 copy of the result (hi = f16(v), lo = f16(v - hi), interleaved per 32
+// channels) at value column s_col0 of rows of lds value columns: what the split16x3 wide convs read, written here so that
+// they need no separate pack pass over the MFA input.
 template <typename T>
 __global__ __launch_bounds__(256) void se_scale_residual_kernel(const T* x, int ldx, const float* gate,
                                                                 const T* res, int ldr, int r_col0,
                                                                 T* y, int ldy, int y_col0,
-                                                                int M, int Tn, int C) {
+                                                                int M, int Tn, int C, _Float16* ys = nullptr, int lds = 0, int s_col0 = 0) {
   constexpr int VEC = 16 / sizeof(T);                 // 4 f32 or 8 f16 channels per lane
   typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
   const int groups = C / VEC;                          // channel groups per row
@@ -119,6 +122,22 @@ __global__ __launch_bounds__(256) void se_scale_residual_kernel(const T* x, int 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o[e] = (T)((float)xv[e] * g[c + e] + (float)rv[e]);
       *reinterpret_cast<vec_t*>(yr + c) = o;
+      if constexpr (sizeof(T) == 4) {
+        if (ys) {
+          typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+          h4v hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float w = __builtin_amdgcn_fmed3f((float)o[e], -65504.f, 65504.f);
+            hi[e] = (_Float16)w;
+            lo[e] = (_Float16)(w - (float)hi[e]);
+          }
+          const int sc = s_col0 + c;
+          _Float16* d = ys + (size_t)m * 2 * lds + 64 * (sc / 32) + (sc % 32);
+          *reinterpret_cast<h4v*>(d) = hi;
+          *reinterpret_cast<h4v*>(d + 32) = lo;
+        }
+      }
     }
   }
 }
@@ -393,6 +412,15 @@ extern "C" int sd_seg_mean_std_f32(const float* x, int ld, int col0, int B, int 
 
 extern "C" int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate, const void* res, int ldr, int r_col0,
                                        void* y, int ldy, int y_col0, int B, int T, int C, int dtype, sd_stream_t stream) {
+  return sd_se_scale_residual_split(x, ldx, gate, res, ldr, r_col0, y, ldy, y_col0, B, T, C, dtype, nullptr, 0, 0, stream);
+}
+
+// library-internal: the same, plus (f32 only) an SD_DT_SPLIT16 copy of the result at value column s_col0 of ys [B*T][lds]
+int sd_se_scale_residual_split(const void* x, int ldx, const float* gate, const void* res, int ldr, int r_col0,
+                               void* y, int ldy, int y_col0, int B, int T, int C, int dtype, void* ys, int lds, int s_col0,
+                               sd_stream_t stream) {
+  if (ys) SD_CHECK_ARG(dtype == SD_DT_F32 && lds % 32 == 0 && s_col0 % 4 == 0 && s_col0 + C <= lds && sd_aligned16(ys),
+                       "sd_se_scale_residual: the split copy needs f32 activations, lds %% 32 == 0, an aligned slice inside the row");
   if (int e = check_cl_dt("sd_se_scale_residual(x)", x, dtype, ldx, 0, C)) return e;
   if (int e = check_cl_dt("sd_se_scale_residual(res)", res, dtype, ldr, r_col0, C)) return e;
   if (int e = check_cl_dt("sd_se_scale_residual(y)", y, dtype, ldy, y_col0, C)) return e;
@@ -412,7 +440,8 @@ extern "C" int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate
                        static_cast<const _Float16*>(res), ldr, r_col0, static_cast<_Float16*>(y), ldy, y_col0, M, T, C);
   else
     hipLaunchKernelGGL(se_scale_residual_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(x), ldx, gate,
-                       static_cast<const float*>(res), ldr, r_col0, static_cast<float*>(y), ldy, y_col0, M, T, C);
+                       static_cast<const float*>(res), ldr, r_col0, static_cast<float*>(y), ldy, y_col0, M, T, C,
+                       static_cast<_Float16*>(ys), lds, s_col0);
   SD_CHECK_LAUNCH("se_scale_residual_kernel");
   return SD_OK;
 }
