@@ -255,6 +255,10 @@ def main():
                          "f32_equivalent_tflops": cs_tf, "note": "achieved = f16 MFMA flops issued (3 per algorithmic flop) per second; the pack pass "
                          "(split16_pack_kernel, f32 -> hi/lo halves, 8 bytes per value) runs in front of every launch and is not in this figure",
                          "launches": cs_n, "avg_launch_ms": cs_ms / max(cs_n, 1), "share_of_step_time": cs_ms * 1e-3 / dts,
+                         "traffic": load_profile_json("traffic_f32s.json").get("conv_gemm_f16_t256_kernel"),
+                         "traffic_source": "file profiles/traffic_f32s.json (separate rocprofv3 --pmc passes of `bench.py --precision f32s`); NOT measured in this run",
+                         "mfma_util_pmc": (load_profile_json("mfma_util_f32s.json").get("conv_gemm_f16_t256_kernel") or {}).get("mfma_util"),
+                         "mfma_util_pmc_source": "file profiles/mfma_util_f32s.json (separate rocprofv3 --pmc pass); NOT measured in this run",
                          "other_conv_kernels": {"kernels": "conv_gemm_f32_kernel (Res2Net convs, attention TDNN, affinity), skinny per-segment layers",
                                                 "launches": ns_n, "achieved": ns_flops / (ns_ms * 1e-3) / 1e12 if ns_ms > 0 else 0.0,
                                                 "share_of_step_time": ns_ms * 1e-3 / dts}},

@@ -480,7 +480,14 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
     char* base = dst + R3_B_BASE + st * R3_B_STAGE;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+#ifdef SD_DIAG_B_TO_REGS      // timing-only diagnostic: the weight pieces as plain 16-byte loads into (discarded) registers: the same
+      // address-path traffic without the LDS write; the MFMAs then read stale weights (results are wrong by construction)
+      f32x4 sink;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(ptr[i]) : "memory");
+      (void)base;
+#else
       SD_GLDS16(ptr[i], base + i * 32 * TROW);
+#endif
       ptr[i] += TBK;
     }
   };

@@ -74,6 +74,11 @@ def test_precision_switch_reaches_the_drop_in_api(dev, tmp_path):
         _, det = db.diarize_audio(p, 0.35, 0.1, 2, 6, return_details=True)
         ref = enc.encode_windows(audio_io.read_audio(p, sr=16000, mono=True)[0], det["window_starts"], 32000)
         assert np.array_equal(det["embeddings"], ref)
+        speech_encode.set_precision("f32s")                      # f32-split16x3 through the same names
+        with pytest.warns(RuntimeWarning):
+            es = speech_encode.ecapa_encode_batch(wav)
+        assert speech_encode.using_ecapa_encoder().engine.precision == "f32s"
+        assert not np.array_equal(es, e32) and _cos_dist(es, e32).max() < 1e-9
         with pytest.raises(ValueError):
             speech_encode.set_precision("bf16")
     finally:

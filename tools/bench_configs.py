@@ -39,11 +39,12 @@ def stream_latency(state_dict, dev, precision, use_graph, hops):
             "hops_per_s": float(1e3 / lat.mean()), "realtime_factor_16ch": float(250.0 / np.percentile(lat, 99))}
 
 
-def host_api_rate(batch, n=32000, reps=100, warm=100):
+def host_api_rate(batch, n=32000, reps=100, warm=100, precision="f32"):
     """The reference's own call: numpy in -> numpy out (H2D + fbank + ECAPA + D2H per call), f32 engine.  Every call
     synchronises, so the card idles between calls and drops its clocks: the first ~100 calls after an idle period run
     30-90 % slower than the steady state (measured 5.6 / 4.3 / 3.0 ms per call of 32 segments); `warm` calls come first."""
     from speech_diarization_amd import speech_encode, synth
+    speech_encode.set_precision(precision)
     wavs = synth.synthetic_segments(5, batch, n)
     for _ in range(warm):
         speech_encode.ecapa_encode_batch(wavs)
@@ -53,7 +54,7 @@ def host_api_rate(batch, n=32000, reps=100, warm=100):
         speech_encode.ecapa_encode_batch(wavs)
         lat.append(time.perf_counter() - t0)
     lat = np.asarray(lat)
-    return {"batch": batch, "n": n, "segments_per_s": batch / float(np.median(lat)), "ms_per_call_p50": float(np.median(lat)) * 1e3,
+    return {"precision": precision, "batch": batch, "n": n, "segments_per_s": batch / float(np.median(lat)), "ms_per_call_p50": float(np.median(lat)) * 1e3,
             "ms_per_call_p90": float(np.percentile(lat, 90)) * 1e3}
 
 
@@ -128,7 +129,7 @@ def main():
     dt = min(t)
     out["micro_batch_sweep"] = {p: micro_batch_sweep(sd, dev, p) for p in ("f32", "f16", "f32s")}
     out["reassignment_windows_1h"] = [reassignment_windows(sd, dev, p) for p in ("f32", "f32s", "f16")]
-    out["host_api_numpy_in_out_f32"] = [host_api_rate(b, n) for b, n in ((32, 32000), (128, 32000), (128, 16000))]
+    out["host_api_numpy_in_out"] = [host_api_rate(b, n, precision=p) for p in ("f32", "f32s", "f16") for b, n in ((32, 32000), (128, 32000), (128, 16000))]
     out["affinity_50k"] = {"ms": dt * 1e3, "tflops": 384.0 * 50000 ** 2 / dt / 1e12, "write_tb_s": 4.0 * 50000 ** 2 / dt / 1e12}
     ops.cosine_affinity(x, out=K, split16=True)
     torch.cuda.synchronize()
