@@ -51,7 +51,7 @@ typedef void* sd_stream_t; /* hipStream_t */
 #define SD_ERR_WORKSPACE (-3)
 #define SD_ERR_HIP (-4)
 
-#define SD_ABI_VERSION 7
+#define SD_ABI_VERSION 8
 
 int sd_abi_version(void);
 /* sizeof of the structs below as this library was compiled (which: 0 sd_conv_args, 1 sd_layer, 2 sd_se_res2_block,
@@ -165,6 +165,9 @@ typedef struct {
    * [mean | std] per segment.  Requirements (SD_ERR_UNSUPPORTED otherwise): T >= 64, cout a multiple of 256,
    * relu / identity activation, per-channel bias, 16-byte aligned slices, no tee. */
   float* colstat;
+  /* sd_conv1d_cl_split16 with f32 x only: the accumulator is multiplied by this (2^-s for weights packed with the
+   * scale 2^s; exact) before the bias; 0 means 1 */
+  float w_scale_inv;
 } sd_conv_args;
 
 int sd_conv1d_cl_f32(const sd_conv_args* args, sd_stream_t stream);
@@ -177,7 +180,11 @@ int sd_conv1d_cl_f16(const sd_conv_args* args, sd_stream_t stream);
  * optionally pre-scaled by a power of two 2^s to keep the low halves of small weights out of the f16 subnormals (the
  * caller then passes bias * 2^s and scale * 2^-s: exact); y: f32.  256x256 tiles (the wide layers: cout >= 256 pays);
  * epilogue as sd_conv1d_cl_f16's 256x256 kernel (tee without tee_add; colstat needs T >= 128).
- * Domain: |x| <= 65504 (larger values are clamped when packed). */
+ * x may also be plain f32 (x_dtype SD_DT_F32; lda, a_col0, cin multiples of 4): the narrow form — a 128x128 tile
+ * kernel that splits the activations while it stages them (no pack pass, any row slice, the full tee / tee_add
+ * epilogue, per-segment bias; no colstat) and multiplies the accumulators by w_scale_inv = 2^-s instead of folding
+ * the weight scale into bias / scale: the Res2Net convs and the attention TDNN of the f32-split16x3 mode.
+ * Domain: |x| <= 65504 (larger values are clamped when packed / staged). */
 int sd_conv1d_cl_split16(const sd_conv_args* args, sd_stream_t stream);
 /* f32 [M][ldx] columns [col0, col0 + C), each multiplied by `mul` (a power of two: exact; 1 for activations) ->
  * SD_DT_SPLIT16 rows out [M][ldo] (ldo value columns, a multiple of 32, >= C rounded up to 32; the padding columns
@@ -242,8 +249,10 @@ typedef struct {
   int cin, cin_pad, cout, taps, dil;
   int w_dtype;        /* SD_DT_F32 or SD_DT_F16 packing of w */
   /* optional second packing of the same layer for sd_conv1d_cl_split16 (NULL: not packed): SD_DT_SPLIT16
-   * [cout][taps][cin rounded up to 32], scaled by 2^s, with bias * 2^s and scale * 2^-s */
-  const void* w_split; const float* bias_split; const float* scale_split;
+   * [cout][taps][cin rounded up to 32], scaled by 2^s.  Wide layers (SD_DT_SPLIT16 activations): bias_split =
+   * bias * 2^s and scale_split = scale * 2^-s carry the scale; narrow layers (f32 activations): bias_split /
+   * scale_split NULL and split_scale_inv = 2^-s goes into sd_conv_args.w_scale_inv */
+  const void* w_split; const float* bias_split; const float* scale_split; float split_scale_inv;
 } sd_layer;
 
 #define SD_MAX_RES2 15

@@ -22,7 +22,7 @@ SD_TUNE_SKINNY_TILES = 1
 SD_TUNE_WIDE_TILES = 2
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
-SD_ABI_VERSION = 7
+SD_ABI_VERSION = 8
 SD_PROF_CONV_GEMM, SD_PROF_FBANK, SD_PROF_CONV_WIDE = 0, 1, 2
 
 
@@ -56,6 +56,7 @@ class sd_conv_args(C.Structure):
         ("tee_add", C.c_void_p), ("ld_ta", C.c_int), ("ta_col0", C.c_int),
         ("x_dtype", C.c_int), ("y_dtype", C.c_int),
         ("colstat", C.c_void_p),
+        ("w_scale_inv", C.c_float),
     ]
 
 
@@ -64,7 +65,7 @@ class sd_layer(C.Structure):
         ("w", C.c_void_p), ("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
         ("cin", C.c_int), ("cin_pad", C.c_int), ("cout", C.c_int), ("taps", C.c_int), ("dil", C.c_int),
         ("w_dtype", C.c_int),
-        ("w_split", C.c_void_p), ("bias_split", C.c_void_p), ("scale_split", C.c_void_p),
+        ("w_split", C.c_void_p), ("bias_split", C.c_void_p), ("scale_split", C.c_void_p), ("split_scale_inv", C.c_float),
     ]
 
 

@@ -214,6 +214,180 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16_kernel(const sd_conv_arg
   sd_store_tile<TO, BM, BN, 256>(p, Cs, LDC, m0, n0, tid, vec);
 }
 
+// ------------------------------------------------------------------------------------------
+// f32-split16x3 for the NARROW outputs (Res2Net 128 -> 128 k = 3, attention TDNN 3C -> 128): the 128x128 register-staged kernel
+// above with the split done WHILE STAGING.  Activations arrive as plain f32 (no pack pass, any lda / a_col0 slice, the tee /
+// tee_add epilogue of the Res2Net chain); a thread loads 4 values (16 bytes), splits them hi = f16(v), lo = f16(v - hi) and
+// stores both halves into the LDS row of its K step: [hi x 32 | lo x 32], the layout of the SD_DT_SPLIT16 weights, which are
+// fetched as they lie.  A K step of 32 values = the four 16-half fragment slices hi0, hi1, lo0, lo1 and six MFMA groups,
+// hi.hi + hi.lo + lo.hi per value slice.  The weights carry a power-of-two scale 2^s (low halves out of the f16 subnormals);
+// the accumulators are multiplied by p.w_scale_inv = 2^-s on their way into the epilogue tile (exact), so bias, per-segment
+// bias and the BatchNorm affine are the layer's own.
+template <typename TO>
+__global__ __launch_bounds__(256, 2) void conv_gemm_split16_n128_kernel(const sd_conv_args p, const int vec) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  _Float16* As = reinterpret_cast<_Float16*>(smem_raw);  // [2][BM][LDP]
+  _Float16* Bs = As + 2 * BM * LDP;                       // [2][BN][LDP]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int n_tiles = (p.cout + BN - 1) / BN;
+  int wg;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_n = wg % n_tiles;
+  const int tile_m = wg / n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // staging role: 8 threads per row, 4 rows per thread.  A: thread c8 owns VALUES 4 c8 .. 4 c8 + 3 of the step's 32 (one 16-byte
+  // f32 load); B: halfs 8 c8 .. 8 c8 + 7 of the 64 (one 16-byte load of the packed weights)
+  const int c8 = tid & 7;
+  const int r0 = tid >> 3;
+  int a_seg[4], a_t[4];
+  const _Float16* wptr[4];
+  const float* aptr[4];
+  const int kvals = p.taps * p.cin_pad;                   // values per output channel; 2 halfs each
+  const _Float16* W = static_cast<const _Float16*>(p.w);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + r0 + 32 * i;
+    m = m < p.M ? m : p.M - 1;
+    const int seg = (m / p.T) * p.T;
+    a_seg[i] = seg;
+    a_t[i] = m - seg;
+    int n = n0 + r0 + 32 * i;
+    n = n < p.cout ? n : p.cout - 1;
+    wptr[i] = W + (size_t)n * 2 * kvals + c8 * 8;
+  }
+  const int nk = p.taps * (p.cin_pad / 32);
+  const int half = p.taps / 2;
+  const float* X = static_cast<const float*>(p.x) + p.a_col0;
+  auto set_tap = [&](int tap) {
+    const int delta = (tap - half) * p.dil;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int tt = a_t[i] + delta;
+      tt = tt < 0 ? -tt : tt;
+      tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
+      aptr[i] = X + (size_t)(a_seg[i] + tt) * p.lda;
+    }
+  };
+  struct Stage { f32x4 a[4]; h8 b[4]; };
+  Stage s0, s1;
+  int ld_tap = 0, ld_c0 = 0;
+  set_tap(0);
+  auto gload = [&](Stage& st) {
+    const int col = ld_c0 + c8 * 4;
+    const int acol = col < p.cin ? col : 0;               // columns past cin meet the zero-filled weight padding
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      st.a[i] = *reinterpret_cast<const f32x4*>(aptr[i] + acol);
+      st.b[i] = *reinterpret_cast<const h8*>(wptr[i]);
+      wptr[i] += BK;
+    }
+    ld_c0 += 32;
+    if (ld_c0 >= p.cin_pad) {
+      ld_c0 = 0;
+      ++ld_tap;
+      if (ld_tap < p.taps) set_tap(ld_tap);
+    }
+  };
+  auto lstore = [&](const Stage& st, int buf) {
+    _Float16* a = As + buf * BM * LDP;
+    _Float16* b = Bs + buf * BN * LDP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w = __builtin_amdgcn_fmed3f(st.a[i][e], -65504.f, 65504.f);
+        hi[e] = (_Float16)w;
+        lo[e] = (_Float16)(w - (float)hi[e]);
+      }
+      *reinterpret_cast<h4*>(a + (r0 + 32 * i) * LDP + c8 * 4) = hi;
+      *reinterpret_cast<h4*>(a + (r0 + 32 * i) * LDP + 32 + c8 * 4) = lo;
+      *reinterpret_cast<h8*>(b + (r0 + 32 * i) * LDP + c8 * 8) = st.b[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 8;
+  struct Frag { h8 a0, a1, b0, b1; };
+  auto fread = [&](const _Float16* a, const _Float16* b, int kk) {
+    Frag f;
+    f.a0 = *reinterpret_cast<const h8*>(a + kk * 16);
+    f.a1 = *reinterpret_cast<const h8*>(a + 32 * LDP + kk * 16);
+    f.b0 = *reinterpret_cast<const h8*>(b + kk * 16);
+    f.b1 = *reinterpret_cast<const h8*>(b + 32 * LDP + kk * 16);
+    return f;
+  };
+  auto mma = [&](const Frag& fa, const Frag& fb) {        // A fragments of fa against B fragments of fb
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.a0, fb.b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.a0, fb.b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.a1, fb.b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.a1, fb.b1, acc[1][1], 0, 0, 0);
+  };
+
+  gload(s0);                 // K step 0
+  if (nk > 1) gload(s1);     // K step 1
+  lstore(s0, 0);
+  if (nk > 2) gload(s0);     // K step 2
+  __syncthreads();
+  int cur = 0;
+  auto kstep = [&](int kt, Stage& st) {
+    const _Float16* a = As + cur * BM * LDP + (wm * 64 + frag_row) * LDP + frag_k;
+    const _Float16* b = Bs + cur * BN * LDP + (wn * 64 + frag_row) * LDP + frag_k;
+    const Frag h0 = fread(a, b, 0);           // hi, values 0-15
+    const Frag l0 = fread(a, b, 2);           // lo, values 0-15
+    mma(h0, h0);
+    const Frag h1 = fread(a, b, 1);           // hi, values 16-31
+    mma(h0, l0);
+    mma(l0, h0);
+    const Frag l1 = fread(a, b, 3);           // lo, values 16-31
+    if (kt + 1 < nk) lstore(st, cur ^ 1);
+    if (kt + 3 < nk) gload(st);
+    mma(h1, h1);
+    mma(h1, l1);
+    mma(l1, h1);
+    __syncthreads();
+    cur ^= 1;
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(kt, s1);
+    if (kt + 1 < nk) kstep(kt + 1, s0);
+  }
+
+  // ---- epilogue: accumulators x 2^-s -> LDS C tile -> sd_store_tile (sd_epilogue.h)
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+  const float alpha = p.w_scale_inv != 0.f ? p.w_scale_inv : 1.f;
+  const int hrow = (lane >> 5) * 4;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int cl = wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + hrow;
+        Cs[rl * LDC + cl] = acc[mi][ni][r] * alpha;
+      }
+    }
+  }
+  __syncthreads();
+  sd_store_tile<TO, BM, BN, 256>(p, Cs, LDC, m0, n0, tid, vec);
+}
+
 #ifdef SD_STAMP
 // diagnostic build only (build_native.py --stamp): per-workgroup cycle counters, read by tools/stamp_t256.py
 __device__ unsigned long long sd_stamp_buf[8192 * 8];
@@ -874,10 +1048,45 @@ extern "C" int sd_conv1d_cl_split16(const sd_conv_args* a, sd_stream_t stream_) 
 // x == w (same packed matrix), M == cout, plain epilogue, 16-byte aligned output rows: upper triangle + mirror (sd_api.hip: the affinity)
 int sd_conv1d_cl_split16_symmetric(const sd_conv_args* a, sd_stream_t stream_) { return conv1d_cl_split16_impl(a, stream_, true); }
 
+// x plain f32 (split while staging): the 128x128 kernel
+static int conv1d_cl_split16_narrow(const sd_conv_args* a, hipStream_t stream) {
+  SD_CHECK_ARG(a->w_dtype == SD_DT_SPLIT16 && a->y_dtype == SD_DT_F32, "sd_conv1d_cl_split16: w must be SD_DT_SPLIT16, y f32");
+  SD_CHECK_ARG(a->M > 0 && a->T > 0 && a->M % a->T == 0, "sd_conv1d_cl_split16: M=%d must be a positive multiple of T=%d", a->M, a->T);
+  SD_CHECK_ARG(a->cin > 0 && a->cin % 4 == 0 && a->cin_pad >= a->cin && a->cin_pad % 32 == 0, "sd_conv1d_cl_split16: cin=%d (a multiple of 4) cin_pad=%d (of 32)", a->cin, a->cin_pad);
+  SD_CHECK_ARG(a->cout > 0 && a->taps >= 1 && (a->taps & 1) && a->dil >= 1 && (a->taps / 2) * a->dil < a->T, "sd_conv1d_cl_split16: cout=%d taps=%d dil=%d T=%d", a->cout, a->taps, a->dil, a->T);
+  SD_CHECK_ARG(a->lda % 4 == 0 && a->a_col0 % 4 == 0 && a->a_col0 + a->cin <= a->lda && sd_aligned16(a->x) && sd_aligned16(a->w),
+               "sd_conv1d_cl_split16: f32 x needs lda / a_col0 multiples of 4, the slice inside the row, 16-byte aligned x and w");
+  SD_CHECK_ARG(a->o_col0 >= 0 && a->o_col0 + a->cout <= a->ldo, "sd_conv1d_cl_split16: output slice outside row");
+  SD_CHECK_ARG(!a->colstat, "sd_conv1d_cl_split16: column statistics come from the 256x256 kernel (SD_DT_SPLIT16 x) only");
+  if (a->tee) {
+    SD_CHECK_ARG(a->tee_lo >= 0 && a->tee_lo < a->tee_hi && a->tee_hi <= a->cout && a->tee_hi - a->tee_lo <= a->ldt,
+                 "sd_conv1d_cl_split16: bad tee range [%d,%d) ldt=%d", a->tee_lo, a->tee_hi, a->ldt);
+    if (a->tee_add)
+      SD_CHECK_ARG(a->ta_col0 >= 0 && a->ta_col0 + (a->tee_hi - a->tee_lo) <= a->ld_ta, "sd_conv1d_cl_split16: tee_add slice outside row");
+  }
+  const long tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->cout + BN - 1) / BN;
+  SD_CHECK_ARG(tiles_m * tiles_n < (1L << 31), "sd_conv1d_cl_split16: grid too large");
+  int vec = a->cout % 8 == 0 && a->ldo % 8 == 0 && a->o_col0 % 8 == 0 && sd_aligned16(a->y);      // sd_store_tile's groups of 8 columns
+  vec = vec && sd_aligned16(a->bias) && sd_aligned16(a->scale) && sd_aligned16(a->shift);
+  if (a->tee) {
+    vec = vec && a->tee_lo % 8 == 0 && a->tee_hi % 8 == 0 && a->ldt % 8 == 0 && sd_aligned16(a->tee);
+    if (a->tee_add) vec = vec && a->ld_ta % 8 == 0 && a->ta_col0 % 8 == 0 && sd_aligned16(a->tee_add);
+  }
+  auto kern = conv_gemm_split16_n128_kernel<float>;
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), STAGE_BYTES));
+  {
+    SdProfScope prof(SD_PROF_CONV_GEMM, stream, 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), STAGE_BYTES, stream, *a, vec);
+  }
+  SD_CHECK_LAUNCH("conv_gemm_split16_n128_kernel");
+  return SD_OK;
+}
+
 static int conv1d_cl_split16_impl(const sd_conv_args* a, sd_stream_t stream_, bool symmetric) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_split16: null args");
   SD_CHECK_ARG(a->x && a->w && a->y, "sd_conv1d_cl_split16: null x/w/y");
+  if (a->x_dtype == SD_DT_F32 && !symmetric) return conv1d_cl_split16_narrow(a, stream);
   SD_CHECK_ARG(a->w_dtype == SD_DT_SPLIT16 && a->x_dtype == SD_DT_SPLIT16 && a->y_dtype == SD_DT_F32,
                "sd_conv1d_cl_split16: x and w must be split-packed (SD_DT_SPLIT16), y f32 (got %d/%d/%d)", a->x_dtype, a->w_dtype, a->y_dtype);
   SD_CHECK_ARG(a->M > 0 && a->T > 0 && a->M % a->T == 0, "sd_conv1d_cl_split16: M=%d must be a positive multiple of T=%d", a->M, a->T);

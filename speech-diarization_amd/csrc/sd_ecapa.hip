@@ -133,6 +133,16 @@ int run_conv(const sd_conv_args& a, sd_stream_t stream) {
 // A wide layer of the f32 schedule: in split16 mode (and when the layer carries the second packing) its f32 input is
 // re-written as SD_DT_SPLIT16 rows (4 bytes per value in, 4 out) and the conv runs on the f16 matrix cores with three
 // products per value pair; otherwise the exact-f32 kernel.
+// A narrow layer of the f32 schedule (Res2Net convs, attention TDNN): in split16 mode, when it carries the second packing, the
+// 128x128 split kernel (f32 activations split while staged; tee / tee_add / per-segment bias as in the exact kernel).
+int run_narrow(const sd_layer& l, sd_conv_args a, bool split, sd_stream_t stream) {
+  if (!(split && l.w_split && !l.bias_split && a.x_dtype == SD_DT_F32 && a.y_dtype == SD_DT_F32 && !a.colstat))
+    return run_conv(a, stream);
+  a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = (l.cin + 31) / 32 * 32;
+  a.w_scale_inv = l.split_scale_inv;
+  return sd_conv1d_cl_split16(&a, stream);
+}
+
 // twin / twin_ld: an SD_DT_SPLIT16 copy of a.x that already exists (same value columns a.a_col0 .. of rows of twin_ld value columns)
 int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, sd_stream_t stream, const void* twin = nullptr, int twin_ld = 0) {
   if (!(split && l.w_split && xs && a.x_dtype == SD_DT_F32 && a.y_dtype == SD_DT_F32 && !(a.tee && a.tee_add) &&
@@ -221,7 +231,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
           a.tee = dst; a.ldt = chunk; a.tee_lo = 0; a.tee_hi = chunk;
           a.tee_add = b.r; a.ld_ta = C; a.ta_col0 = (j + 1) * chunk;
         }
-        SD_TRY(run_conv(a, stream));
+        SD_TRY(run_narrow(blk.res2[j - 1], a, split, stream));
       }
     }
     // tdnn2; the SE squeeze (mean over T) comes out of its epilogue as per-tile column sums where the
@@ -265,7 +275,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     SD_TRY(run_conv(g, stream));
     sd_conv_args a = conv_of(w->asp_tdnn_h, b.h, dt, Cm, 0, b.a1, dt, w->att_channels, 0, M, T, SD_ACT_RELU);
     a.bias = b.gbias; a.bias_per_seg = 1; a.act2 = SD_ACT_TANH;
-    SD_TRY(run_conv(a, stream));
+    SD_TRY(run_narrow(w->asp_tdnn_h, a, split, stream));
     // asp.conv + softmax over T + weighted statistics: one kernel where the geometry allows (the
     // [M][3C] logits are then never stored), else the conv followed by the pooling kernel
     static const bool fuse_ok = [] {     // SD_ASP_FUSED=0: A/B switch for measurements

@@ -82,6 +82,7 @@ class EcapaWeights:
             raise ValueError(f"precision must be 'f32', 'f16' or 'f32s' (f32-split16x3), got {precision!r}")
         self.device = device
         self.precision = precision
+        self.split_narrow = True      # f32s: also the narrow convs on the split kernel (False: wide layers only, as first built)
         self.cfg: EcapaConfig = config_from_state_dict(state_dict)
         cfg = self.cfg
         if len(set(cfg.channels[:-1])) != 1 or cfg.channels[-1] != cfg.n_blocks * cfg.channels[0]:
@@ -151,14 +152,20 @@ class EcapaWeights:
         else:
             L.scale, L.shift = None, None
         L.cin, L.cin_pad, L.cout, L.taps, L.dil = cin, packed.shape[2], cout, k, dil
-        # "f32s": the wide frame-level layers (stem, tdnn1, tdnn2, MFA: 86 % of the flops) get a second, split-f16 packing
-        if self.precision == "f32s" and not per_segment and cout >= 1024 and affine is not None and bias is not None:
-            ws, s = pack_conv_weight_split16(w)
-            L.w_split = self._dev(ws, np.float16)
-            L.bias_split = self._dev(bias * np.float32(2.0 ** s))
-            L.scale_split = self._dev(affine[0] * np.float32(2.0 ** -s))
-        else:
-            L.w_split, L.bias_split, L.scale_split = None, None, None
+        # "f32s": the frame-level conv layers get a second, split-f16 packing.  Wide outputs (stem, tdnn1, tdnn2, MFA: 86 % of
+        # the flops; 256x256 kernel, SD_DT_SPLIT16 activations) carry the weight scale 2^s in bias * 2^s / scale * 2^-s; narrow
+        # ones (Res2Net convs, attention TDNN; 128x128 kernel that splits f32 activations while staging) pass 2^-s to the kernel
+        L.w_split, L.bias_split, L.scale_split, L.split_scale_inv = None, None, None, 0.0
+        if self.precision == "f32s" and not per_segment and cin % 4 == 0:
+            if cout >= 1024 and affine is not None and bias is not None:
+                ws, s = pack_conv_weight_split16(w)
+                L.w_split = self._dev(ws, np.float16)
+                L.bias_split = self._dev(bias * np.float32(2.0 ** s))
+                L.scale_split = self._dev(affine[0] * np.float32(2.0 ** -s))
+            elif cout <= 256 and self.split_narrow:
+                ws, s = pack_conv_weight_split16(w)
+                L.w_split = self._dev(ws, np.float16)
+                L.split_scale_inv = float(2.0 ** -s)
 
 
 class EmbeddingEngine:

@@ -114,39 +114,57 @@ def pack_weight_split16(w: torch.Tensor | np.ndarray, device):
     return torch.from_numpy(packed).to(device), s
 
 
-def conv1d_cl_split16(x: torch.Tensor, w_split: torch.Tensor, w_shift: int, T: int, *, cin: int, dil: int = 1, bias=None, act=None,
-                      scale=None, shift=None, a_col0: int = 0, out: torch.Tensor | None = None, o_col0: int = 0,
-                      tee: torch.Tensor | None = None, tee_lo: int = 0, tee_hi: int = 0, colstat: torch.Tensor | None = None) -> torch.Tensor:
-    """The "f32-split16x3" conv: f32 x [M, lda] -> f32 y [M, ldo] at f32-level accuracy on the f16 matrix cores
-    (`sd_split16_pack_f32` + `sd_conv1d_cl_split16`).  `w_split`, `w_shift` from `pack_weight_split16`; bias / scale /
-    shift are the layer's ordinary f32 vectors (the 2^s of the weight scaling is folded in here)."""
-    _need_cuda(x, w_split, bias, scale, shift, out, tee, colstat)
+def conv1d_cl_split16(x: torch.Tensor, w_split: torch.Tensor, w_shift: int, T: int, *, cin: int, dil: int = 1, bias=None, bias_per_seg=False,
+                      act=None, scale=None, shift=None, act2=None, a_col0: int = 0, out: torch.Tensor | None = None, o_col0: int = 0,
+                      tee: torch.Tensor | None = None, tee_lo: int = 0, tee_hi: int = 0, tee_add: torch.Tensor | None = None, ta_col0: int = 0,
+                      colstat: torch.Tensor | None = None, narrow: bool = False) -> torch.Tensor:
+    """The "f32-split16x3" conv: f32 x [M, lda] -> f32 y [M, ldo] at f32-level accuracy on the f16 matrix cores.
+    `w_split`, `w_shift` from `pack_weight_split16`; bias / scale / shift are the layer's ordinary f32 vectors.
+    Default (wide outputs): `sd_split16_pack_f32` + the 256x256 kernel, the 2^s of the weight scaling folded into bias and scale here.
+    `narrow=True`: the 128x128 kernel that splits the f32 activations while staging them (no pack pass; tee_add, per-segment bias and
+    act2 allowed, no colstat), the 2^-s passed as `w_scale_inv`."""
+    _need_cuda(x, w_split, bias, scale, shift, out, tee, tee_add, colstat)
     lib = N.load()
     cout, taps, chunks, _ = w_split.shape
     cp = chunks * 32
     M = x.shape[0]
-    xs = split16_pack(x, a_col0, cin)
     if out is None:
         out = torch.empty((M, cout), dtype=torch.float32, device=x.device)
     f = float(2.0 ** w_shift)
-    bias_s = None if bias is None else bias * f
-    scale_s = (torch.full((cout,), 1.0 / f, dtype=torch.float32, device=x.device) if scale is None else scale / f)
     a = N.sd_conv_args()
-    a.x, a.lda, a.a_col0 = xs.data_ptr(), cp, 0
+    if narrow:
+        if x.dtype != torch.float32 or x.stride(1) != 1:
+            raise TypeError("x must be f32 with contiguous channels")
+        keep = (x,)
+        a.x, a.lda, a.a_col0, a.x_dtype = x.data_ptr(), x.stride(0), a_col0, N.SD_DT_F32
+        a.bias, a.scale = _ptr(bias), _ptr(scale)
+        a.w_scale_inv = 1.0 / f
+    else:
+        if bias_per_seg or act2 is not None or tee_add is not None:
+            raise ValueError("per-segment bias / act2 / tee_add belong to the narrow kernel (narrow=True)")
+        xs = split16_pack(x, a_col0, cin)
+        bias_s = None if bias is None else bias * f
+        scale_s = (torch.full((cout,), 1.0 / f, dtype=torch.float32, device=x.device) if scale is None else scale / f)
+        keep = (xs, bias_s, scale_s)
+        a.x, a.lda, a.a_col0, a.x_dtype = xs.data_ptr(), cp, 0, N.SD_DT_SPLIT16
+        a.bias, a.scale = _ptr(bias_s), _ptr(scale_s)
     a.w, a.w_dtype = w_split.data_ptr(), N.SD_DT_SPLIT16
-    a.x_dtype, a.y_dtype = N.SD_DT_SPLIT16, N.SD_DT_F32
+    a.y_dtype = N.SD_DT_F32
     a.y, a.ldo, a.o_col0 = out.data_ptr(), out.stride(0), o_col0
     a.M, a.T = M, T
     a.cin, a.cin_pad, a.cout, a.taps, a.dil = cin, cp, cout, taps, dil
-    a.bias, a.bias_per_seg = _ptr(bias_s), 0
-    a.act, a.act2 = _ACT[act], _ACT[None]
-    a.scale, a.shift = _ptr(scale_s), _ptr(shift)
+    a.bias_per_seg = int(bool(bias_per_seg))
+    a.act, a.act2 = _ACT[act], _ACT[act2]
+    a.shift = _ptr(shift)
     if tee is not None:
         a.tee, a.ldt, a.tee_lo, a.tee_hi = tee.data_ptr(), tee.stride(0), tee_lo, tee_hi
+        if tee_add is not None:
+            a.tee_add, a.ld_ta, a.ta_col0 = tee_add.data_ptr(), tee_add.stride(0), ta_col0
     if colstat is not None:
         a.colstat = colstat.data_ptr()
     with torch.cuda.device(x.device):
         N.check(lib.sd_conv1d_cl_split16(C.byref(a), _stream(x)), "sd_conv1d_cl_split16")
+    del keep
     return out
 
 

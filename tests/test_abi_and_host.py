@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_the_header_sizes():
     # plain C layout: pointers 8, ints 4; sizes are what the .so was compiled with (checked on the GPU by use)
-    assert C.sizeof(_native.sd_layer) == 4 * 8 + 6 * 4 + 3 * 8
+    assert C.sizeof(_native.sd_layer) == 4 * 8 + 6 * 4 + 3 * 8 + 8          # (+ split_scale_inv and tail padding)
     lib = _native.load()
     for which, st in enumerate((_native.sd_conv_args, _native.sd_layer, _native.sd_se_res2_block, _native.sd_ecapa_weights)):
         assert lib.sd_sizeof(which) == C.sizeof(st), st.__name__          # the compiled C layout, not a guess

@@ -98,6 +98,73 @@ def test_conv1d_cl_split16_tee_and_colstat(dev):
     assert (st[:, :cout].double() - mean).abs().max() < 1e-5 and (st[:, cout:].double() - std).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("B,T,cin,cout,k,dil", [
+    (3, 201, 128, 128, 3, 2),        # Res2Net conv (block 1)
+    (5, 101, 128, 128, 3, 4),        # 1 s windows, dilation 4: reflect gathers across tile edges
+    (2, 201, 3072, 128, 1, 1),       # attention TDNN
+    (1, 40, 96, 200, 3, 1),          # partial tiles both ways, cin padded 96 -> 96, cout not a multiple of 128
+    (2, 77, 36, 64, 5, 1),           # cin % 32 != 0 (zero-filled weight padding), k = 5
+])
+def test_conv1d_cl_split16_narrow_is_as_accurate_as_exact_f32(dev, B, T, cin, cout, k, dil):
+    """The 128x128 kernel that splits its f32 activations while staging them (Res2Net convs, attention TDNN of the f32-split16x3
+    mode), against float64 and next to the exact-f32 kernel on the same inputs."""
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(B * 17 + T + cin)
+    x = torch.randn(B * T, cin, generator=g) * 2.0
+    x[:, ::5] *= 1e-3
+    w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    ref = torch.relu(_ref_conv_cl(x.double(), w.double(), b.double(), T, dil)) * scale.double() + shift.double()
+    ws, s = ops.pack_weight_split16(w, dev)
+    kw = dict(cin=cin, dil=dil, bias=b.to(dev), act="relu", scale=scale.to(dev), shift=shift.to(dev))
+    got = ops.conv1d_cl_split16(x.to(dev), ws, s, T, narrow=True, **kw)
+    f32 = ops.conv1d_cl(x.to(dev), ops.pack_weight(w, dev), T, **kw)
+    torch.cuda.synchronize()
+    e_split = (got.cpu().double() - ref).abs().max().item()
+    e_f32 = (f32.cpu().double() - ref).abs().max().item()
+    top = ref.abs().max().item()
+    print(f"\n[narrow {B}x{T} {cin}->{cout} k{k} d{dil}] max abs error vs float64: split16x3 {e_split:.3e}, exact f32 {e_f32:.3e} (output max {top:.2f})")
+    assert e_split < 2e-6 * max(1.0, top) and e_split < 8.0 * e_f32 + 1e-7 * top
+
+
+def test_conv1d_cl_split16_narrow_epilogues(dev):
+    """What the Res2Net chain and the attention TDNN ask of the narrow kernel: an input slice of a wider buffer, the output into a
+    slice, tee + tee_add (the c_{j+1} + y_j add), per-segment bias and the tanh after the affine — against the exact-f32 kernel."""
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, C, hid = 3, 57, 256, 64
+    xbig = torch.randn(B * T, C, generator=g)
+    w = torch.randn(hid, hid, 3, generator=g) / 14
+    x_d = xbig.to(dev)
+    ws, s = ops.pack_weight_split16(w, dev)
+    outs = []
+    for split in (True, False):
+        out = torch.zeros(B * T, C, device=dev)
+        tee = torch.zeros(B * T, hid, device=dev)
+        kw = dict(cin=hid, dil=2, act="relu", a_col0=64, out=out, o_col0=64, tee=tee, tee_lo=0, tee_hi=hid, tee_add=x_d, ta_col0=128)
+        if split:
+            ops.conv1d_cl_split16(x_d, ws, s, T, narrow=True, **kw)
+        else:
+            ops.conv1d_cl(x_d, ops.pack_weight(w, dev), T, **kw)
+        outs.append((out, tee))
+    (o1, t1), (o2, t2) = outs
+    assert (o1 - o2).abs().max() < 2e-6 * o2.abs().max() and (t1 - t2).abs().max() < 2e-6 * t2.abs().max()
+    assert o1[:, :64].abs().max() == 0 and o1[:, 128:].abs().max() == 0
+    # attention TDNN form: per-segment bias, relu -> affine -> tanh
+    cin, cout = 512, 128
+    x = torch.randn(B * T, cin, generator=g).to(dev)
+    w2 = torch.randn(cout, cin, 1, generator=g) / np.sqrt(cin)
+    gb = torch.randn(B, cout, generator=g).to(dev)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+    ws2, s2 = ops.pack_weight_split16(w2, dev)
+    kw = dict(cin=cin, bias=gb, bias_per_seg=True, act="relu", scale=scale, shift=shift, act2="tanh")
+    ys = ops.conv1d_cl_split16(x, ws2, s2, T, narrow=True, **kw)
+    y32 = ops.conv1d_cl(x, ops.pack_weight(w2, dev), T, **kw)
+    assert (ys - y32).abs().max() < 2e-6
+
+
 @pytest.mark.parametrize("B,n", [(4, 32000), (5, 16000), (2, 100000), (3, 9600)])
 def test_ecapa_split16_full_geometry_matches_oracle(dev, B, n):
     """The exact-f32 path's full-geometry test (tests/test_gpu_fbank_ecapa.py) with the SAME bars, on the split16x3 engine;
