@@ -143,12 +143,25 @@ int run_narrow(const sd_layer& l, sd_conv_args a, bool split, sd_stream_t stream
   return sd_conv1d_cl_split16(&a, stream);
 }
 
+// Small launches of the C-wide layers (measured, tools/probe_split16.py: 1024 -> 1024 at 32 segments 0.063 ms on the 128x128 split
+// kernel against 0.085 ms for pack + 256x256 kernel, 0.041 against 0.079 at 16; from 64 segments up, and for 3C -> 3C always, the
+// 256x256 kernel wins): at most 128 tiles of 256x256 and cout <= 1024 -> the narrow kernel, which has no column statistics.
+bool wide_goes_narrow(const sd_layer& l, int M) {
+  const long tiles = (long)((M + 255) / 256) * ((l.cout + 255) / 256);
+  return l.cout <= 1024 && tiles <= 128;
+}
+
 // twin / twin_ld: an SD_DT_SPLIT16 copy of a.x that already exists (same value columns a.a_col0 .. of rows of twin_ld value columns)
 int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, sd_stream_t stream, const void* twin = nullptr, int twin_ld = 0) {
   if (!(split && l.w_split && xs && a.x_dtype == SD_DT_F32 && a.y_dtype == SD_DT_F32 && !(a.tee && a.tee_add) &&
         !(a.colstat && a.T < 128)))
     return run_conv(a, stream);
   const int cp = (l.cin + 31) / 32 * 32;
+  if (wide_goes_narrow(l, a.M) && !a.colstat && l.cin % 4 == 0 && a.lda % 4 == 0 && a.a_col0 % 4 == 0) {
+    a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = cp;           // f32 x stays: split while staged; the folded 2^s
+    a.bias = l.bias_split; a.scale = l.scale_split; a.w_scale_inv = 0.f;    // form of bias / scale serves this kernel too
+    return sd_conv1d_cl_split16(&a, stream);
+  }
   if (twin && l.cin % 32 == 0 && a.a_col0 % 32 == 0) {
     a.x = twin; a.lda = twin_ld; a.x_dtype = SD_DT_SPLIT16;            // (a_col0 stays: the twin has the layout of the f32 buffer)
   } else {
@@ -238,7 +251,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // geometry allows (the Res2Net scratch s0 is dead and holds them), else from a pass over t2
     {
       sd_conv_args a = conv_of(blk.tdnn2, b.r, dt, C, 0, b.t2, dt, C, 0, M, T, SD_ACT_RELU);
-      const bool stat = colstat_ok && T >= (split ? 128 : 64) && C % 256 == 0 &&
+      const bool stat = colstat_ok && T >= (split ? 128 : 64) && C % 256 == 0 && !(split && blk.tdnn2.w_split && wide_goes_narrow(blk.tdnn2, M)) &&
                         sd_colstat_floats(M, C) * sizeof(float) <= (size_t)M * chunk * es;
       if (stat) a.colstat = static_cast<float*>(b.s0);
       SD_TRY(run_wide(blk.tdnn2, a, split, b.xs, stream));
@@ -261,7 +274,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   // epilogue (column sums in r, dead since the last block's tdnn2)
   {
     sd_conv_args a = conv_of(w->mfa, b.xcat, dt, Cm, 0, b.h, dt, Cm, 0, M, T, SD_ACT_RELU);
-    const bool stat = colstat_ok && T >= (split ? 128 : 64) && Cm % 256 == 0 &&
+    const bool stat = colstat_ok && T >= (split ? 128 : 64) && Cm % 256 == 0 && !(split && w->mfa.w_split && wide_goes_narrow(w->mfa, M)) &&
                       sd_colstat_floats(M, Cm) * sizeof(float) <= (size_t)M * C * es;
     if (stat) a.colstat = static_cast<float*>(b.r);
     SD_TRY(run_wide(w->mfa, a, split, b.xs, stream, b.xcs, Cm));

@@ -47,11 +47,13 @@ def main():
     ws, s = ops.pack_weight_split16(w, dev)
     bs, msp = timeit(lambda: ops.conv1d_cl_split16(x, ws, s, a.T, out=out, **kw), a.reps)
     bp, mp = timeit(lambda: ops.split16_pack(x, 0, a.cin), a.reps)
+    bn, mn = timeit(lambda: ops.conv1d_cl_split16(x, ws, s, a.T, out=out, narrow=True, **kw), a.reps)
     xh = x.half(); w16 = ops.pack_weight(w, dev, torch.float16); o16 = torch.empty(M, a.cout, device=dev, dtype=torch.float16)
     b16, m16 = timeit(lambda: ops.conv1d_cl(xh, w16, a.T, out=o16, **kw), a.reps)
     print(f"M={M} {a.cin}->{a.cout} k{a.taps}: exact f32 {m32:.3f} ms ({flops / m32 / 1e9:.0f} TFLOP/s) | split16x3 pack+conv {msp:.3f} ms "
           f"({flops / msp / 1e9:.0f} f32-equivalent TFLOP/s), pack alone {mp:.3f} ms ({M * a.cin * 8 / mp / 1e6:.0f} GB/s), conv alone {msp - mp:.3f} ms "
-          f"({flops / (msp - mp) / 1e9:.0f}; {3 * flops / (msp - mp) / 1e9:.0f} f16 TFLOP/s issued) | f16 {m16:.3f} ms ({flops / m16 / 1e9:.0f} TFLOP/s)")
+          f"({flops / (msp - mp) / 1e9:.0f}; {3 * flops / (msp - mp) / 1e9:.0f} f16 TFLOP/s issued) | narrow split kernel (no pack) {mn:.3f} ms "
+          f"({flops / mn / 1e9:.0f}) | f16 {m16:.3f} ms ({flops / m16 / 1e9:.0f} TFLOP/s)")
 
 
 if __name__ == "__main__":
