@@ -244,10 +244,12 @@ def main():
         cosd = 1.0 - torch.nn.functional.cosine_similarity(embs.double(), emb32.double(), dim=1)
         cs_tf = cs_flops / (cs_ms * 1e-3) / 1e12 if cs_ms > 0 else 0.0
         extra_split = {
-            "note": "same step with the wide layers (stem, tdnn1, tdnn2, MFA: 86 % of the flops) on the f16 matrix cores at f32-level accuracy: "
-                    "every f32 operand value split hi + lo (two f16), three products hi.hi + hi.lo + lo.hi per value pair on v_mfma_f32_16x16x32_f16, "
-                    "f32 accumulation (2^-22 relative per product; exact f32 MFMA: 2^-24); activations stay f32 in HBM, every other kernel is the "
-                    "exact-f32 one.  Passes the exact-f32 path's parity tests (tests/test_gpu_split16.py).  NOT the headline value",
+            "note": "same step with the frame-level conv layers on the f16 matrix cores at f32-level accuracy: every f32 operand value split hi + lo "
+                    "(two f16), three products hi.hi + hi.lo + lo.hi per value pair, f32 accumulation (2^-22 relative per product; exact f32 MFMA: "
+                    "2^-24).  Wide layers (stem, tdnn1, tdnn2, MFA: 86 % of the flops): 256x256 LDS-DMA ring kernel on SD_DT_SPLIT16 rows; narrow layers "
+                    "(Res2Net convs, attention TDNN): 128x128 kernel that splits the f32 activations while staging them.  Activations stay f32 in HBM; the "
+                    "fused attention conv + pooling kernel, SE, statistics and per-segment layers are the exact-f32 ones.  Passes the exact-f32 path's parity "
+                    "tests (tests/test_gpu_split16.py).  NOT the headline value",
             "value": n_total * args.steps / dts, "unit": "segments/s", "ms_per_step": dts / args.steps * 1e3, "dtype": "f32-split16x3",
             "max_cosine_distance_vs_f32_path": float(cosd.max().item()),
             "roofline": {"kernel": "conv_gemm_f16_t256_kernel<SPLIT>", "bound": "mfma",
@@ -259,7 +261,7 @@ def main():
                          "traffic_source": "file profiles/traffic_f32s.json (separate rocprofv3 --pmc passes of `bench.py --precision f32s`); NOT measured in this run",
                          "mfma_util_pmc": (load_profile_json("mfma_util_f32s.json").get("conv_gemm_f16_t256_kernel") or {}).get("mfma_util"),
                          "mfma_util_pmc_source": "file profiles/mfma_util_f32s.json (separate rocprofv3 --pmc pass); NOT measured in this run",
-                         "other_conv_kernels": {"kernels": "conv_gemm_f32_kernel (Res2Net convs, attention TDNN, affinity), skinny per-segment layers",
+                         "other_conv_kernels": {"kernels": "conv_gemm_split16_n128_kernel (Res2Net convs, attention TDNN; f32-equivalent TFLOP/s), conv_gemm_f32_kernel (affinity)",
                                                 "launches": ns_n, "achieved": ns_flops / (ns_ms * 1e-3) / 1e12 if ns_ms > 0 else 0.0,
                                                 "share_of_step_time": ns_ms * 1e-3 / dts}},
         }
@@ -342,9 +344,15 @@ def main():
                 "rows": a_rows, "cols": n_total, "avg_call_ms": affinity_ms, "share_of_step_time": affinity_ms * 1e-3 * args.steps / dt,
                 "bytes": {"bound": "hbm", "achieved": a_bytes / (affinity_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": a_bytes / (affinity_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": a_bytes},
-                "flops": {"bound": "mfma", "achieved": a_flops / (affinity_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": a_flops / (affinity_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops": a_flops,
-                          "note": "algorithmic-equivalent: the full-matrix flops; the symmetric path computes the upper triangle only"},
+                # the whole-matrix (symmetric) path computes the 128x128 tiles on and above the diagonal only: nt (nt + 1) / 2 of nt^2
+                "flops": (lambda nt, full: {
+                    "bound": "mfma", "achieved": a_flops * full / (affinity_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": a_flops * full / (affinity_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                    "computed_flops": a_flops * full, "algorithmic_flops": a_flops,
+                    "algorithmic_equivalent_tflops": a_flops / (affinity_ms * 1e-3) / 1e12,
+                    "note": "achieved / frac count the flops actually executed (upper-triangle tiles when the block is the whole matrix); "
+                            "algorithmic_equivalent_tflops counts the full matrix's 384 N^2"})(
+                    (n_total + 127) // 128, ((((n_total + 127) // 128) + 1) / (2.0 * ((n_total + 127) // 128))) if (a_rows == n_total) else 1.0),
                 "timing": "torch.cuda.Event pairs on the launch stream around every timed call",
             }
         if extra_f16 is not None:

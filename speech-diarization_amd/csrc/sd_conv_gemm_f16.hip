@@ -727,16 +727,23 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
       P3_READ_B(fb0, sb, so0);                                               // Bhi
       if (kt > 0) { P3_MMA(1, fa1, fb1); }                                   // deferred hi(g1).Blo of step kt - 1
       if (bload && kt + 1 < nk) issue_b(sb ^ 1);
+#ifndef SD_SPLIT_A_SLOT
+#define SD_SPLIT_A_SLOT 0        // behind which of the step's half-slices the activation waves issue their pieces (A/B builds)
+#endif
       P3_READ_A(fa1, sa, so0, 0);                                            // hi(g0)
       P3_MMA(0, fa0, fb0);                                                   // lo(g0).Bhi
-      if (!bload && kt + 2 < nk) issue_a(sa2);
+      if (SD_SPLIT_A_SLOT == 0 && !bload && kt + 2 < nk) issue_a(sa2);
       P3_READ_B(fb1, sb, so1);                                               // Blo
       P3_READ_A(fa0, sa, so1, 1);                                            // lo(g1)
       P3_MMA(0, fa1, fb0);                                                   // hi(g0).Bhi
+      if (SD_SPLIT_A_SLOT == 1 && !bload && kt + 2 < nk) issue_a(sa2);
       P3_MMA(0, fa1, fb1);                                                   // hi(g0).Blo
+      if (SD_SPLIT_A_SLOT == 2 && !bload && kt + 2 < nk) issue_a(sa2);
       P3_READ_A(fa1, sa, so0, 1);                                            // hi(g1)
       P3_MMA(1, fa0, fb0);                                                   // lo(g1).Bhi
+      if (SD_SPLIT_A_SLOT == 3 && !bload && kt + 2 < nk) issue_a(sa2);
       P3_MMA(1, fa1, fb0);                                                   // hi(g1).Bhi
+      if (SD_SPLIT_A_SLOT == 4 && !bload && kt + 2 < nk) issue_a(sa2);
       sa = sa == 2 ? 0 : sa + 1;
       sb ^= 1;
     }

@@ -6,13 +6,14 @@ set -eo pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/refresh; mkdir -p $out
 common="--no-f16-extra --no-split-extra --no-cpu-baseline"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/f32 -- python3 bench.py --steps 3 --warmup 1 $common > $out/f32.log 2>&1
-echo "f32 stats done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/f16 -- python3 bench.py --precision f16 --steps 3 --warmup 1 $common > $out/f16.log 2>&1
-echo "f16 stats done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/f32s -- python3 bench.py --precision f32s --steps 3 --warmup 1 $common > $out/f32s.log 2>&1
-echo "f32s stats done"
-for p in f32 f16 f32s; do
+precisions=${PRECISIONS:-"f32 f16 f32s"}          # PRECISIONS="f32s" bash tools/refresh_profiles.sh: only that engine
+rm -rf $out
+mkdir -p $out
+for p in $precisions; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$p -- python3 bench.py --precision $p --steps 3 --warmup 1 $common > $out/$p.log 2>&1
+  echo "$p stats done"
+done
+for p in $precisions; do
   for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
     tag=$(echo $c | cut -d' ' -f1)
     timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${tag}_$p -- python3 bench.py --precision $p --steps 1 --warmup 0 $common > $out/pmc_${tag}_$p.log 2>&1
