@@ -197,6 +197,10 @@ int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int C, float m
 /* SD_TUNE_WIDE_TILES: sd_conv1d_cl_f32 launches with cout >= 1024 and at least `value` 256x256 tiles run the 256x256 ring
  * kernel (default 1024 = four rounds over the CUs; 0 = whenever the layer qualifies; negative = restore the default). */
 #define SD_TUNE_WIDE_TILES 2
+/* SD_TUNE_F16_NARROW_TILES: launches of layers with cout == 1024 (the C-wide layers) of sd_conv1d_cl_f16, and of the
+ * f32-split16x3 schedule, with at most `value` 256x256 tiles run the 128x128 kernel (two workgroups per CU fill the chip better than a
+ * fraction of one round of big tiles: default 128 = up to 32 two-second segments; 0 = always the 256x256 kernel; negative = default). */
+#define SD_TUNE_F16_NARROW_TILES 3
 int sd_set_tuning(int key, long value);
 /* floats needed for sd_conv_args.colstat */
 size_t sd_colstat_floats(int M, int cout);

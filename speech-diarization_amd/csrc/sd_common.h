@@ -10,6 +10,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int sd_set_error(int code, const char* fmt, ...);
+// SD_TUNE_F16_NARROW_TILES (sd_set_tuning): C-wide f16 / split16 layers with at most this many 256x256 tiles take the 128x128 kernel
+#include <atomic>
+std::atomic<long>& sd_f16_narrow_tiles();
 // library-internal entry points
 int sd_conv1d_cl_f32_symmetric(const sd_conv_args* a, sd_stream_t stream);   // sd_conv_gemm.hip: x == w, upper triangle + mirror
 int sd_conv1d_cl_split16_symmetric(const sd_conv_args* a, sd_stream_t stream); // sd_conv_gemm_f16.hip: x == w, upper triangle + mirror

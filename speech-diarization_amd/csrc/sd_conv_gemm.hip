@@ -658,6 +658,10 @@ extern "C" int sd_set_tuning(int key, long value) {
     g_wide_from.store(value < 0 ? 1024L : value, std::memory_order_relaxed);
     return SD_OK;
   }
+  if (key == SD_TUNE_F16_NARROW_TILES) {
+    sd_f16_narrow_tiles().store(value < 0 ? 128L : value, std::memory_order_relaxed);
+    return SD_OK;
+  }
   return sd_set_error(SD_ERR_ARG, "sd_set_tuning: unknown key %d", key);
 }
 

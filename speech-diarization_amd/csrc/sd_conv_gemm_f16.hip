@@ -932,6 +932,11 @@ extern "C" int sd_debug_read_stamps(unsigned long long* out, int n) {
 }
 #endif
 
+std::atomic<long>& sd_f16_narrow_tiles() {
+  static std::atomic<long> v{128L};
+  return v;
+}
+
 extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_f16: null args");
@@ -980,7 +985,11 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
     if (!e) return -1;
     return e[0] == 'r' ? 0 : e[0] == 't' ? 2 : -1;
   }();
-  const bool wide = a->cout >= 1024;
+  // ... except for small launches of the C-wide layers (round 3, tools/sweep_f16.py: 1024 -> 1024 at 16 / 32 segments 0.024 / 0.030 ms
+  // on the 128x128 kernel against 0.035 / 0.038; from 64 segments up, and for 3C -> 3C always, the 256x256 kernel wins): at most 128
+  // tiles of 256x256 -> two workgroups of 128x128 per CU fill the chip better than a fraction of one round of big tiles
+  const long t256 = (long)((a->M + TBM - 1) / TBM) * ((a->cout + TBN - 1) / TBN);
+  const bool wide = a->cout >= 1024 && !(a->cout <= 1024 && t256 <= sd_f16_narrow_tiles().load(std::memory_order_relaxed));
   const int choice = forced >= 0 ? forced : (wide ? 2 : 0);
   // (the 256x256 kernel: no tee_add epilogue, and column statistics only for tiles that span <= 2 segments)
   if (xa && choice == 2 && !(a->tee && a->tee_add) && !(a->colstat && a->T < 128)) {

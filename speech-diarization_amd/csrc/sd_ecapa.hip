@@ -148,7 +148,7 @@ int run_narrow(const sd_layer& l, sd_conv_args a, bool split, sd_stream_t stream
 // 256x256 kernel wins): at most 128 tiles of 256x256 and cout <= 1024 -> the narrow kernel, which has no column statistics.
 bool wide_goes_narrow(const sd_layer& l, int M) {
   const long tiles = (long)((M + 255) / 256) * ((l.cout + 255) / 256);
-  return l.cout <= 1024 && tiles <= 128;
+  return l.cout <= 1024 && tiles <= sd_f16_narrow_tiles().load(std::memory_order_relaxed);     // SD_TUNE_F16_NARROW_TILES (default 128)
 }
 
 // twin / twin_ld: an SD_DT_SPLIT16 copy of a.x that already exists (same value columns a.a_col0 .. of rows of twin_ld value columns)

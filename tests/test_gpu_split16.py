@@ -12,6 +12,17 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["wide256", "auto"], autouse=True)
+def split_kernel_choice(request):
+    """"wide256": the C-wide layers of the f32-split16x3 schedule always on the 256x256 kernel (at these test sizes "auto" sends them
+    to the 128x128 split kernel: launches of at most 128 big tiles)."""
+    from speech_diarization_amd import _native as N
+    lib = N.load()
+    N.check(lib.sd_set_tuning(N.SD_TUNE_F16_NARROW_TILES, 0 if request.param == "wide256" else -1), "sd_set_tuning")
+    yield request.param
+    N.check(lib.sd_set_tuning(N.SD_TUNE_F16_NARROW_TILES, -1), "sd_set_tuning")
+
+
 def _cos_dist(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
