@@ -247,8 +247,9 @@ def main():
             "note": "same step with the frame-level conv layers on the f16 matrix cores at f32-level accuracy: every f32 operand value split hi + lo "
                     "(two f16), three products hi.hi + hi.lo + lo.hi per value pair, f32 accumulation (2^-22 relative per product; exact f32 MFMA: "
                     "2^-24).  Wide layers (stem, tdnn1, tdnn2, MFA: 86 % of the flops): 256x256 LDS-DMA ring kernel on SD_DT_SPLIT16 rows; narrow layers "
-                    "(Res2Net convs, attention TDNN): 128x128 kernel that splits the f32 activations while staging them.  Activations stay f32 in HBM; the "
-                    "fused attention conv + pooling kernel, SE, statistics and per-segment layers are the exact-f32 ones.  Passes the exact-f32 path's parity "
+                    "(Res2Net convs, attention TDNN): 128x128 kernel that splits the f32 activations while staging them; the attention conv inside the fused "
+                    "pooling kernel: a1 split once in LDS.  Activations stay f32 in HBM; SE, statistics, softmax / pooling and the per-segment layers are "
+                    "exact f32.  Passes the exact-f32 path's parity "
                     "tests (tests/test_gpu_split16.py).  NOT the headline value",
             "value": n_total * args.steps / dts, "unit": "segments/s", "ms_per_step": dts / args.steps * 1e3, "dtype": "f32-split16x3",
             "max_cosine_distance_vs_f32_path": float(cosd.max().item()),

@@ -267,32 +267,53 @@ int launch_f16(const void* a1, const void* wc, const void* h, int ldh, int B, in
 // (12-wave workgroups; 168 registers mean spills and no h prefetch: 8.5 ms).
 constexpr int FLD = AK + 4;   // LDS row stride of the f32 a1 tile in floats (528 B: conflict-free ds_read_b128)
 
-template <int NT>   // 16-frame tiles: T <= 16 * NT
+// SPLIT (the f32-split16x3 mode; tensors stay f32): the logits product on v_mfma_f32_16x16x32_f16 with every operand value split
+// hi + lo and three products per fragment pair (hi.hi + hi.lo + lo.hi, f32 accumulation; 2^-22 relative per product): the a1 tile is
+// split ONCE when it is staged (LDS: a hi plane and a lo plane of [frames][128 + 8] halfs), the 16 x 128 weight rows of a group
+// are split in registers as they arrive (scaled by 2^8: |w| ~ 0.1, the low halves stay out of the f16 subnormals; the logits
+// take 2^-8 back), and a (frame tile, 32 k) pair costs 3 MFMAs of 16 cycles instead of 8 f32 MFMAs of 32.  The accumulator layout
+// (lane = frame, 4 channels per lane) is the f32 instruction's, so softmax and pooling below are shared.
+constexpr int SLD = AK + 8;   // LDS row stride of a split a1 plane in halfs (272 B)
+
+template <int NT, bool SPLIT = false>   // 16-frame tiles: T <= 16 * NT
 __global__ __launch_bounds__(512, 2) void asp_attend_pool_f32_kernel(const float* __restrict__ a1, const float* __restrict__ wc,
                                                                      const float* __restrict__ h, int ldh, int Tn, int C, int cpb,
                                                                      float eps, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float sf[];   // [NT * 16][FLD]
+  extern __shared__ __attribute__((aligned(16))) float sf[];   // [NT * 16][FLD]   (SPLIT: two planes of [NT * 16][SLD] halfs)
   const int cblocks = C / cpb;
   const int b = blockIdx.x / cblocks, cblk = blockIdx.x % cblocks;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, quad = lane >> 4;
+  _Float16* const s_hi = reinterpret_cast<_Float16*>(sf);
+  _Float16* const s_lo = s_hi + NT * 16 * SLD;
   {
     const float* ab = a1 + (size_t)b * Tn * AK;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     for (int p = tid; p < NT * 16 * (AK / 4); p += 512) {
       const int row = p / (AK / 4), q = (p % (AK / 4)) * 4;
-      *reinterpret_cast<f32x4*>(sf + row * FLD + q) = row < Tn ? *reinterpret_cast<const f32x4*>(ab + (size_t)row * AK + q) : z;
+      const f32x4 v = row < Tn ? *reinterpret_cast<const f32x4*>(ab + (size_t)row * AK + q) : z;
+      if constexpr (SPLIT) {
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+        *reinterpret_cast<h4*>(s_hi + row * SLD + q) = hi;
+        *reinterpret_cast<h4*>(s_lo + row * SLD + q) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(sf + row * FLD + q) = v;
+      }
     }
   }
   __syncthreads();
 
   const int ngroups = cpb / 16;                       // groups of this workgroup; wave w takes w, w + 8, ...
   const float* hl = h + ((size_t)b * Tn + col) * ldh + (size_t)cblk * cpb + 4 * quad;
-  const float* wl = wc + ((size_t)cblk * cpb + col) * AK + 4 * quad;
+  // weight fragments: f32 MFMA: lane (channel col, k = 16 ks + 4 quad + e);  SPLIT: lane (channel col, k = 32 s + 8 quad + e)
+  const float* wl = wc + ((size_t)cblk * cpb + col) * AK + (SPLIT ? 8 : 4) * quad;
   const float* al = sf + col * FLD + 4 * quad;
   auto load_w = [&](int g, f32x4* dst) {
 #pragma unroll
-    for (int ks = 0; ks < AK / 16; ++ks) dst[ks] = *reinterpret_cast<const f32x4*>(wl + (size_t)g * 16 * AK + ks * 16);
+    for (int ks = 0; ks < AK / 16; ++ks)
+      dst[ks] = *reinterpret_cast<const f32x4*>(wl + (size_t)g * 16 * AK + (SPLIT ? (ks >> 1) * 32 + (ks & 1) * 4 : ks * 16));
   };
   f32x4 wf[AK / 16];
   if (wid < ngroups) load_w(wid, wf);
@@ -308,6 +329,44 @@ __global__ __launch_bounds__(512, 2) void asp_attend_pool_f32_kernel(const float
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (SPLIT) {
+      constexpr float WS = 256.f;
+      h8 whi[4], wlo[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float w = WS * wf[2 * s4 + (e >> 2)][e & 3];
+          whi[s4][e] = (_Float16)w;
+          wlo[s4][e] = (_Float16)(w - (float)whi[s4][e]);
+        }
+      const _Float16* ahp = s_hi + col * SLD + 8 * quad;
+      const _Float16* alp = s_lo + col * SLD + 8 * quad;
+      // (frame tile j, k slice s4): two 16-byte LDS reads, three MFMAs; the reads of pair u + 1 are issued in front of the MFMAs of
+      // pair u (two fragment sets)
+      auto rd = [&](int u, h8& ah, h8& alo_) {
+        const int s4 = u / NT, j = u % NT;
+        ah = *reinterpret_cast<const h8*>(ahp + j * 16 * SLD + s4 * 32);
+        alo_ = *reinterpret_cast<const h8*>(alp + j * 16 * SLD + s4 * 32);
+      };
+      h8 ah0, al0;
+      rd(0, ah0, al0);
+#pragma unroll
+      for (int u = 0; u < 4 * NT; ++u) {
+        const int s4 = u / NT, j = u % NT;
+        h8 ah1 = ah0, al1 = al0;
+        if (u + 1 < 4 * NT) rd(u + 1, ah1, al1);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s4], ah0, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s4], al0, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[s4], ah0, acc[j], 0, 0, 0);
+        ah0 = ah1; al0 = al1;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two LDS reads of the next pair first ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then this pair's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] *= (1.0f / WS);
+    } else {
     // Two frame tiles per step (their MFMAs alternate, so no MFMA waits on its predecessor's
     // 40-cycle result latency) and the next step's two B fragments in flight; the scheduling
     // barriers keep the compiler from hoisting all NT * 8 LDS reads (416 registers) above the MFMAs.
@@ -331,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void asp_attend_pool_f32_kernel(const float
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two LDS reads of the next step first ...
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then this step's MFMAs
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     // the next group's weight fragments load under the softmax phase (wf is dead from here on)
     if (g + 8 < ngroups) load_w(g + 8, wf);
@@ -395,10 +455,10 @@ __global__ __launch_bounds__(512, 2) void asp_attend_pool_f32_kernel(const float
   }
 }
 
-template <int NT>
+template <int NT, bool SPLIT = false>
 int launch_f32(const void* a1, const void* wc, const void* h, int ldh, int B, int T, int C, float eps, float* out, hipStream_t s) {
-  auto kern = asp_attend_pool_f32_kernel<NT>;
-  const size_t lds = (size_t)NT * 16 * FLD * sizeof(float);
+  auto kern = asp_attend_pool_f32_kernel<NT, SPLIT>;
+  const size_t lds = SPLIT ? (size_t)2 * NT * 16 * SLD * sizeof(_Float16) : (size_t)NT * 16 * FLD * sizeof(float);
   const int cpb = C % 512 == 0 ? 512 : 256;
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * (C / cpb))), dim3(512), lds, s, static_cast<const float*>(a1),
@@ -410,7 +470,7 @@ int launch_f32(const void* a1, const void* wc, const void* h, int ldh, int B, in
 }  // namespace
 
 extern "C" int sd_asp_attend_pool_supported(int dtype, int T, int C, int att) {
-  return (dtype == SD_DT_F16 || dtype == SD_DT_F32) && att == AK && C > 0 && C % CPB == 0 && T > 0 && T <= 256;
+  return (dtype == SD_DT_F16 || dtype == SD_DT_F32 || dtype == SD_DT_SPLIT16) && att == AK && C > 0 && C % CPB == 0 && T > 0 && T <= 256;
 }
 
 extern "C" int sd_asp_attend_pool_dt(const void* a1, const void* wc, const void* h, int dtype, int ldh, int B, int T, int C,
@@ -424,6 +484,12 @@ extern "C" int sd_asp_attend_pool_dt(const void* a1, const void* wc, const void*
   SD_CHECK_ARG(sd_aligned16(a1) && sd_aligned16(wc) && sd_aligned16(h) && sd_aligned16(out), "sd_asp_attend_pool_dt: pointers must be 16-byte aligned");
   if (B == 0) return SD_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == SD_DT_SPLIT16) {       // f32 tensors, the logits product as three f16 MFMA products per value pair (f32-split16x3 mode)
+    if (T <= 64) return launch_f32<4, true>(a1, wc, h, ldh, B, T, C, eps, out, s);
+    if (T <= 128) return launch_f32<8, true>(a1, wc, h, ldh, B, T, C, eps, out, s);
+    if (T <= 208) return launch_f32<13, true>(a1, wc, h, ldh, B, T, C, eps, out, s);
+    return launch_f32<16, true>(a1, wc, h, ldh, B, T, C, eps, out, s);
+  }
   if (dtype == SD_DT_F32) {
     if (T <= 64) return launch_f32<4>(a1, wc, h, ldh, B, T, C, eps, out, s);
     if (T <= 128) return launch_f32<8>(a1, wc, h, ldh, B, T, C, eps, out, s);

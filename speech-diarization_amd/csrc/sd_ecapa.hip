@@ -298,7 +298,8 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     const bool fused = fuse_ok && w->asp_conv.taps == 1 && w->asp_conv.cin_pad == w->att_channels &&
                        sd_asp_attend_pool_supported(dt, T, Cm, w->att_channels);
     if (fused) {
-      SD_TRY(sd_asp_attend_pool_dt(b.a1, w->asp_conv.w, b.h, dt, Cm, B, T, Cm, w->att_channels, w->asp_eps, b.pooled, stream));
+      // (split16 mode: the same f32 tensors, the logits product on the f16 matrix cores with split operands)
+      SD_TRY(sd_asp_attend_pool_dt(b.a1, w->asp_conv.w, b.h, split ? SD_DT_SPLIT16 : dt, Cm, B, T, Cm, w->att_channels, w->asp_eps, b.pooled, stream));
     } else {
       sd_conv_args c = conv_of(w->asp_conv, b.a1, dt, w->att_channels, 0, b.e, dt, Cm, 0, M, T, SD_ACT_NONE);
       SD_TRY(run_conv(c, stream));

@@ -250,7 +250,7 @@ def asp_pool(logit: torch.Tensor, h: torch.Tensor, B: int, T: int, eps: float = 
     return out
 
 
-def asp_attend_pool(a1: torch.Tensor, wc_packed: torch.Tensor, h: torch.Tensor, B: int, T: int, eps: float = 1e-12) -> torch.Tensor:
+def asp_attend_pool(a1: torch.Tensor, wc_packed: torch.Tensor, h: torch.Tensor, B: int, T: int, eps: float = 1e-12, split16: bool = False) -> torch.Tensor:
     """softmax_T(a1 @ wc^T) weighted mean / std of h in one kernel (`asp.conv` + pooling of speechbrain's
     AttentiveStatisticsPooling): a1 [B*T, att], wc_packed from `pack_weight`, h [B*T, C] -> f32 [B, 2C].
     Raises for geometries the fused kernel does not cover (see `asp_attend_pool_supported`)."""
@@ -260,6 +260,10 @@ def asp_attend_pool(a1: torch.Tensor, wc_packed: torch.Tensor, h: torch.Tensor, 
     if a1.dtype != h.dtype or wc_packed.dtype != h.dtype:
         raise ValueError("a1, wc and h must share a dtype")
     dt = N.SD_DT_F16 if h.dtype == torch.float16 else N.SD_DT_F32
+    if split16:       # f32 tensors, the logits product as three f16 MFMA products per value pair (the f32-split16x3 mode)
+        if h.dtype != torch.float32:
+            raise ValueError("split16 takes f32 tensors")
+        dt = N.SD_DT_SPLIT16
     a1 = a1.contiguous()
     out = torch.empty((B, 2 * C_), dtype=torch.float32, device=h.device)
     with torch.cuda.device(h.device):

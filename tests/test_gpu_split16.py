@@ -229,3 +229,26 @@ def test_split16_identical_clusters_and_properties_at_full_size(dev):
     cd = 1.0 - torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)
     print(f"\n5000 segments: split16x3 vs exact f32 max cosine distance {float(cd.max()):.2e}")
     assert float(cd.max()) < 1e-6
+
+
+@pytest.mark.parametrize("B,T,Cc", [(3, 201, 512), (2, 101, 256), (4, 33, 256), (2, 256, 256), (5, 1, 256), (1, 129, 3072), (2, 208, 1024), (2, 17, 256)])
+def test_fused_attention_pooling_split16_matches_f64(dev, B, T, Cc):
+    """asp.conv + softmax over T + weighted mean / std with the logits product on split operands (three f16 MFMA products per value
+    pair): the exact-f32 kernel's bars against float64, and next to the exact-f32 kernel on the same inputs."""
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    att = 128
+    a1 = torch.tanh(torch.randn(B * T, att, generator=g))
+    wc = torch.randn(Cc, att, 1, generator=g) / 4
+    h = torch.randn(B * T, Cc, generator=g) * 1.5 + 0.3
+    wp = ops.pack_weight(wc, dev)
+    got = ops.asp_attend_pool(a1.to(dev), wp, h.to(dev), B, T, split16=True).cpu().double()
+    f32 = ops.asp_attend_pool(a1.to(dev), wp, h.to(dev), B, T).cpu().double()
+    a = torch.softmax((a1.double() @ wc[:, :, 0].double().T).view(B, T, Cc), dim=1)
+    hr = h.double().view(B, T, Cc)
+    mu = (a * hr).sum(1)
+    sd = torch.sqrt(((a * (hr - mu[:, None]) ** 2).sum(1)).clamp_min(1e-12))
+    assert (got[:, :Cc] - mu).abs().max() < 2e-5
+    if T > 1:
+        assert (got[:, Cc:] - sd).abs().max() < 2e-5
+    assert (got[:, :Cc] - mu).abs().max() < 4.0 * (f32[:, :Cc] - mu).abs().max() + 1e-6
