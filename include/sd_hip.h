@@ -341,6 +341,10 @@ int sd_sim_argmax_f32(const float* w, int ldw, int N, int D, const float* c, int
                       int32_t* best, float* score, sd_stream_t stream);
 
 /* ------------------------------------------- score normalisation / smoothing */
+/* Precondition of the three operators below: FINITE inputs.  A NaN is not treated as numpy treats it (the radix select
+ * orders a positive NaN above every number, so it would enter the top-k and poison mean / std; the Viterbi recurrence
+ * never selects a NaN candidate where np.argmax returns its index): "exact path equality" with the reference holds for
+ * finite scores.  K == 1 in sd_viterbi_f32: pass log_move = 0 (the reference divides by K - 1 = 0 there). */
 
 /* Per row of x [rows][ld] (n valid columns): mean and population std of its k largest values
  * (np.sort(x, axis=1)[:, -k:].mean / .std of `asnorm_scores` [REF diar_diag.py:201-204]; k is clipped to n).

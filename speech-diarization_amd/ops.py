@@ -335,7 +335,8 @@ def sim_argmax(w: torch.Tensor, c: torch.Tensor):
 
 
 def topk_mean_std(x: torch.Tensor, k: int) -> torch.Tensor:
-    """[rows, n] f32 -> [rows, 2] = mean and population std of each row's k largest values (k clipped to n)."""
+    """[rows, n] f32 -> [rows, 2] = mean and population std of each row's k largest values (k clipped to n).
+    Precondition: finite values (a NaN would be selected into the top-k and poison the statistics)."""
     _need_cuda(x)
     x = x.float()
     if x.stride(1) != 1:
@@ -350,7 +351,7 @@ def topk_mean_std(x: torch.Tensor, k: int) -> torch.Tensor:
 def asnorm_scores(query: torch.Tensor, centers: torch.Tensor, cohort: torch.Tensor, topk: int = 200) -> torch.Tensor:
     """`asnorm_scores` [REF diar_diag.py:196-208] on the device: rows scaled by 1 / (norm + 1e-9), the three cosine
     products on the f32 matrix cores (the operator behind the 1x1 convs, T = 1), top-k cohort statistics per row,
-    z-normalisation against the query's and the centre's cohort scores, averaged.  f32 [nq, nr]."""
+    z-normalisation against the query's and the centre's cohort scores, averaged.  f32 [nq, nr].  Precondition: finite inputs."""
     _need_cuda(query, centers, cohort)
     lib = N.load()
     qn, rn, cn = (l2norm_rows(t, eps_add=1e-9) for t in (query, centers, cohort))
@@ -373,7 +374,9 @@ def asnorm_scores(query: torch.Tensor, centers: torch.Tensor, cohort: torch.Tens
 
 def viterbi(scores: torch.Tensor, alpha: float = 0.995) -> torch.Tensor:
     """`viterbi_hmm` [REF diar_diag.py:231-247] on the device: scores f32 [T, K <= 64] -> int32 path [T]; the two
-    transition log-probabilities are formed as the reference forms them (float64 log, rounded to f32)."""
+    transition log-probabilities are formed as the reference forms them (float64 log, rounded to f32).  Precondition: finite
+    scores (a NaN candidate is never selected here, np.argmax would return it); K == 1 uses log_move = 0 where the reference
+    divides by K - 1 = 0."""
     _need_cuda(scores)
     scores = scores.contiguous().float()
     T, K = scores.shape
