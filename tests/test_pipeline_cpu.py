@@ -115,3 +115,46 @@ def test_streaming_ring_is_written_in_place_and_reads_the_last_window():
         st.push(torch.zeros(3, 7))
     with pytest.raises(ValueError):
         StreamingEmbedder(eng, channels=1, window_s=0.5, hop_s=0.3, sr=1600, use_graph=False)
+
+
+def test_windows_read_in_place_are_the_rows_the_host_path_gathers(monkeypatch, tmp_path):
+    """The GPU path of SCD and of `diarize_audio` hands `encode_windows` a signal and START OFFSETS instead of gathered rows
+    (`sd_fbank_windows_f32` reads the windows in place).  Without a GPU: a stand-in encoder behind `using_ecapa_encoder` that gathers
+    `signal[s : s + n]` itself (zero padded) must give exactly what the literal host path gives — i.e. the offsets are the rows of
+    `frame_audio` / `gather_windows`."""
+    from speech_diarization_amd import anti_stick_diarize as asd, speech_encode
+
+    def cpu_encode(w):
+        w = np.asarray(w, dtype=np.float32)
+        return np.stack([np.abs(np.fft.rfft(r, 382))[:192] for r in w]).astype(np.float32)
+
+    class FakeEncoder:
+        def __init__(self):
+            self.calls = []
+
+        def encode_windows(self, signal, starts, n, rows_per_call=8192, to_host=True):
+            signal = np.asarray(signal, dtype=np.float32)
+            rows = np.zeros((len(starts), n), np.float32)
+            for i, s in enumerate(np.asarray(starts)):
+                piece = signal[int(s): int(s) + n]
+                rows[i, : len(piece)] = piece
+            self.calls.append((len(signal), len(starts), n))
+            return cpu_encode(rows)
+
+    fake = FakeEncoder()
+    monkeypatch.setattr(speech_encode, "using_ecapa_encoder", lambda device="cuda": fake)
+    host_cos = asd.adjacent_cosine
+    monkeypatch.setattr(asd, "adjacent_cosine", lambda e, use_gpu: host_cos(e, False))
+    conv = synth.synthetic_conversation(40.0, 3, seed=4)
+    segs = [asd.Segment(0.37, 9.81), asd.Segment(10.2, 10.9), asd.Segment(12.0, 31.456), asd.Segment(33.3, 39.99)]
+    a = asd.scd_split_segments(conv.wav, 16000, segs, thr=1.0)                       # "GPU" path: offsets
+    b = asd.scd_split_segments(conv.wav, 16000, segs, thr=1.0, encode=cpu_encode)    # host path: frame_audio rows
+    assert [(s.start, s.end) for s in a] == [(s.start, s.end) for s in b] and len(a) > len(segs)
+    assert len(fake.calls) == 1 and fake.calls[0][0] == len(conv.wav) and fake.calls[0][2] == 16000   # ONE call, the whole signal
+    # diarize_audio: embeddings from offsets == embeddings of gather_windows (incl. the zero-padded tail window)
+    monkeypatch.setattr(db, "cosine_affinity", lambda e, use_gpu: asd.cosine_affinity(e, False))
+    wav = tmp_path / "m.wav"
+    audio_io.write_wav16(wav, conv.wav, conv.sr)
+    _, det_g = db.diarize_audio(wav, 0.35, 0.1, 2, 6, return_details=True)
+    _, det_c = db.diarize_audio(wav, 0.35, 0.1, 2, 6, return_details=True, encoder=cpu_encode)
+    assert np.array_equal(det_g["embeddings"], det_c["embeddings"]) and np.array_equal(det_g["labels"], det_c["labels"])
