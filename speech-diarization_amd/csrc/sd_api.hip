@@ -163,9 +163,9 @@ extern "C" int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row
 // The same matrix at the f16 matrix-core rate with f32-level accuracy (BASELINE configs[4]: the 50k x 50k affinity): the
 // normalised rows, scaled by 2^4 (low halves of typical entries ~0.07 stay clear of the f16 subnormals), are packed once as
 // SD_DT_SPLIT16 (hi = f16(v), lo = f16(v - hi) per 32 values) and the product is the three-MFMA form hi.hi + hi.lo + lo.hi of
-// sd_conv1d_cl_split16 with the SAME packed matrix on both sides; the epilogue takes the 2^-8 back.  The whole matrix is
-// computed on and above the diagonal only and every off-diagonal 256 x 256 tile is stored twice, as is and transposed through
-// LDS (whole 512-byte runs); what is left is writing 4 N^2 bytes.
+// the SAME packed matrix on both sides; the epilogue takes the 2^-8 back.  The whole matrix is computed on and above the diagonal only
+// (sd_affinity.hip: 128 x 128 tiles, two workgroups per CU) and every off-diagonal tile is stored twice from the same accumulators, both
+// copies as 256-byte runs; what is left is writing 4 N^2 bytes.
 static int pad32s(int d) { return (d + 31) & ~31; }
 
 extern "C" size_t sd_cosine_split16_workspace_bytes(int N, int D) {
@@ -204,6 +204,10 @@ extern "C" int sd_cosine_affinity_rows_split16(const float* x, int N, int D, int
   if (e != SD_OK) return e;
   e = sd_split16_pack_f32(xn, Dp, 0, N, D, 16.f, xs, Ds, stream);
   if (e != SD_OK) return e;
+  static const bool sym = [] { const char* e = sd_experiment_env("SD_AFFINITY_SYM"); return !e || atoi(e) != 0; }();
+  if (sym && N % 4 == 0 && ldo % 4 == 0 && sd_aligned16(out) && row_lo == 0 && row_hi == N)
+    return sd_affinity_sym_split16(xs, 2 * Ds, N, Ds / 32, out, ldo, 1.0f / 256.0f, stream);       // sd_affinity.hip: upper triangle + mirror
+  // a row block, or rows that cannot take 16-byte stores: every tile of the block through the conv kernel, the 2^-8 as its per-column scale
   hipLaunchKernelGGL(fill_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), sc, N, 1.0f / 256.0f);
   SD_CHECK_LAUNCH("fill_f32_kernel");
   sd_conv_args a = {};
@@ -214,8 +218,5 @@ extern "C" int sd_cosine_affinity_rows_split16(const float* x, int N, int D, int
   a.cin = D; a.cin_pad = Ds; a.cout = N; a.taps = 1; a.dil = 1;
   a.act = SD_ACT_NONE; a.act2 = SD_ACT_NONE;
   a.scale = sc;
-  static const bool sym = [] { const char* e = sd_experiment_env("SD_AFFINITY_SYM"); return !e || atoi(e) != 0; }();
-  const bool aligned = N % 8 == 0 && ldo % 8 == 0 && sd_aligned16(out);      // the register epilogue's 16-byte stores
-  if (sym && aligned && row_lo == 0 && row_hi == N) return sd_conv1d_cl_split16_symmetric(&a, stream);
   return sd_conv1d_cl_split16(&a, stream);
 }

@@ -569,11 +569,9 @@ __device__ __forceinline__ void sd_direct_epilogue(const sd_conv_args& p, ACC (&
 //   lo(g0).Bhi, hi(g0).Bhi, hi(g0).Blo, lo(g1).Bhi, hi(g1).Bhi, hi(g1).Blo
 // reads every fragment set once, keeps two A sets and both B sets live, and ends on Blo, so that the deferred last
 // half-slice does not collide with the next step's first B read (Bhi).
-// SYM (x == w, M == cout: the N x N cosine affinity): only tiles on and above the diagonal are launched (row-major over the upper
-// triangle, so consecutive workgroups still share an A panel); a tile is stored as is from the registers and, off the diagonal,
-// a second time transposed: the accumulators go through the (now idle) LDS ring as [256 columns][128 rows] halves, so that the
-// mirrored rows leave as whole 512-byte runs.  K[i][j] and K[j][i] are the same bits.
-template <typename TO, bool DIRECT, bool SPLIT = false, bool SYM = false>
+// (The N x N cosine affinity had a SYM form of this kernel in round 3: upper-triangle tiles + an LDS-transposed mirror; superseded by
+// sd_affinity.hip, whose 128 x 128 tiles leave two workgroups on a CU: 3.2 -> 2.3 ms for 50 k x 50 k.)
+template <typename TO, bool DIRECT, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec) {
   constexpr int TBK = 64;
   constexpr int TROW = 128;
@@ -597,18 +595,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  int tile_n = wg % n_tiles;
-  int tile_m = wg / n_tiles;
-  if constexpr (SYM) {
-    // wg-th tile of the upper triangle, rows first: row i starts at i n - i (i - 1) / 2
-    const float b = 2.f * (float)n_tiles + 1.f;
-    int i = (int)((b - sqrtf(b * b - 8.f * (float)wg)) * 0.5f);
-    i = i < 0 ? 0 : (i > n_tiles - 1 ? n_tiles - 1 : i);
-    while (i > 0 && i * n_tiles - i * (i - 1) / 2 > wg) --i;
-    while (i + 1 < n_tiles && (i + 1) * n_tiles - (i + 1) * i / 2 <= wg) ++i;
-    tile_m = i;
-    tile_n = i + (wg - (i * n_tiles - i * (i - 1) / 2));
-  }
+  const int tile_n = wg % n_tiles;
+  const int tile_m = wg / n_tiles;
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
   // staging role: within its group of 256 threads, thread (r0 = lt / 8, ps = lt % 8) fills physical 16-byte slot ps of rows
@@ -798,64 +786,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #endif
   if constexpr (DIRECT) {
     sd_direct_epilogue<TO>(p, acc, m0 + wm * 128, n0 + wn * 64, fr, fq);
-    if constexpr (SYM) {
-      {
-        // (a diagonal tile mirrors too: its strictly lower part is overwritten by the transposed upper part, because the three
-        // products of an element and of its transpose are summed in opposite orders and differ in the last bit; the
-        // s_waitcnt vmcnt(0) in front of the first barrier orders the two stores of such an element: the direct stores are
-        // acknowledged before any mirrored store is issued)
-        const bool diag = tile_n == tile_m;                    // workgroup-uniform
-        constexpr int LDT = 132;                               // [256 output columns][128 rows + 4]: 16-byte aligned rows
-        static_assert(TBN * LDT * 4 <= R3_LDS_BYTES, "transposed half tile must fit in the ring");
-        float* Ct = reinterpret_cast<float*>(smem_raw);
-        float* const Y = static_cast<float*>(p.y) + p.o_col0;
-        const float lo = p.act == SD_ACT_RELU ? 0.f : -INFINITY;
-        // LDS-only barriers below (s_waitcnt lgkmcnt(0) + s_barrier): the library barrier carries an s_waitcnt vmcnt(0) and made
-        // every tile wait until its 256 KB of direct stores, then each mirrored half, had reached memory (50 k x 50 k: 3.3 ms)
-        if (diag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // ... except where the two stores of an element must be ordered
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // every wave has read its last fragments
-#pragma unroll 1
-        for (int hm = 0; hm < 2; ++hm) {
-          if (wm == hm) {
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj) {
-              const int cl = wn * 64 + 16 * nj + 4 * fq;      // tile-relative output column of acc[..][nj][0]
-              const int c = n0 + cl < p.cout ? n0 + cl : 0;
-              const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-              const f32x4 sv = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
-              const f32x4 hv = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-              for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  Ct[(cl + r) * LDT + 16 * mi + fr] = fmaxf(acc[mi][nj][r] + bv[r], lo) * sv[r] + hv[r];
-            }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          // row c of the image = column n0 + c of the tile = ROW n0 + c of the mirrored block, columns m0 + 128 hm + [0, 128)
-          const int colbase = m0 + 128 * hm + (tid & 31) * 4;
-#pragma unroll 4
-          for (int it = 0; it < 16; ++it) {
-            const int c = it * 16 + (tid >> 5);
-            const int orow = n0 + c;
-            if (orow < p.cout) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(Ct + c * LDT + (tid & 31) * 4);
-              float* dst = Y + (size_t)orow * p.ldo + colbase;
-              const int lim = diag ? (orow < p.M ? orow : p.M) : p.M;        // columns < lim are written
-              if (colbase + 3 < lim) *reinterpret_cast<f32x4*>(dst) = v;
-              else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (colbase + e < lim) dst[e] = v[e];
-              }
-            }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image has been read (the stores themselves stay in flight)
-          __builtin_amdgcn_s_barrier();
-        }
-      }
-    }
   } else {
   __syncthreads();
   
@@ -891,18 +821,16 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #endif
 }
 
-template <typename TO, bool DIRECT, bool SPLIT = false, bool SYM = false>
+template <typename TO, bool DIRECT, bool SPLIT = false>
 int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
-  const long tiles_m = SYM ? ((long)(a->cout + TBN - 1) / TBN + 1) / 2 : (a->M + TBM - 1) / TBM;      // (SYM: nt (nt + 1) / 2 tiles in all,
-  const long tiles_n = SYM ? 0 : (a->cout + TBN - 1) / TBN;                                           //  computed below)
-  auto kern = conv_gemm_f16_t256_kernel<TO, DIRECT, SPLIT, SYM>;
+  const long tiles_m = (a->M + TBM - 1) / TBM;
+  const long tiles_n = (a->cout + TBN - 1) / TBN;
+  auto kern = conv_gemm_f16_t256_kernel<TO, DIRECT, SPLIT>;
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), R3_LDS_BYTES));
   {
     // work = the algorithmic (f32-equivalent) flops: a split row carries cin / 2 values
     SdProfScope prof(SD_PROF_CONV_WIDE, stream, (SPLIT ? 1.0 : 2.0) * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
-    const long nt = (a->cout + TBN - 1) / TBN;
-    const long grid = SYM ? nt * (nt + 1) / 2 : tiles_m * tiles_n;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), R3_LDS_BYTES, stream, *a, vec);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), R3_LDS_BYTES, stream, *a, vec);
   }
   SD_CHECK_LAUNCH("conv_gemm_f16_t256_kernel");
   return SD_OK;
@@ -1059,10 +987,6 @@ extern "C" int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int
   return SD_OK;
 }
 
-static int conv1d_cl_split16_impl(const sd_conv_args* a, sd_stream_t stream_, bool symmetric);
-extern "C" int sd_conv1d_cl_split16(const sd_conv_args* a, sd_stream_t stream_) { return conv1d_cl_split16_impl(a, stream_, false); }
-// x == w (same packed matrix), M == cout, plain epilogue, 16-byte aligned output rows: upper triangle + mirror (sd_api.hip: the affinity)
-int sd_conv1d_cl_split16_symmetric(const sd_conv_args* a, sd_stream_t stream_) { return conv1d_cl_split16_impl(a, stream_, true); }
 
 // x plain f32 (split while staging): the 128x128 kernel
 static int conv1d_cl_split16_narrow(const sd_conv_args* a, hipStream_t stream) {
@@ -1098,11 +1022,11 @@ static int conv1d_cl_split16_narrow(const sd_conv_args* a, hipStream_t stream) {
   return SD_OK;
 }
 
-static int conv1d_cl_split16_impl(const sd_conv_args* a, sd_stream_t stream_, bool symmetric) {
+extern "C" int sd_conv1d_cl_split16(const sd_conv_args* a, sd_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_split16: null args");
   SD_CHECK_ARG(a->x && a->w && a->y, "sd_conv1d_cl_split16: null x/w/y");
-  if (a->x_dtype == SD_DT_F32 && !symmetric) return conv1d_cl_split16_narrow(a, stream);
+  if (a->x_dtype == SD_DT_F32) return conv1d_cl_split16_narrow(a, stream);
   SD_CHECK_ARG(a->w_dtype == SD_DT_SPLIT16 && a->x_dtype == SD_DT_SPLIT16 && a->y_dtype == SD_DT_F32,
                "sd_conv1d_cl_split16: x and w must be split-packed (SD_DT_SPLIT16), y f32 (got %d/%d/%d)", a->x_dtype, a->w_dtype, a->y_dtype);
   SD_CHECK_ARG(a->M > 0 && a->T > 0 && a->M % a->T == 0, "sd_conv1d_cl_split16: M=%d must be a positive multiple of T=%d", a->M, a->T);
@@ -1135,11 +1059,6 @@ static int conv1d_cl_split16_impl(const sd_conv_args* a, sd_stream_t stream_, bo
   k.cin = 2 * a->cin_pad; k.cin_pad = 2 * a->cin_pad;
   k.x_dtype = SD_DT_F16; k.w_dtype = SD_DT_F16;
   const bool plain = vec && (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg && !a->tee;
-  if (symmetric) {
-    SD_CHECK_ARG(plain && !a->colstat && a->x == a->w && a->M == a->cout && a->T == 1 && a->taps == 1 && a->a_col0 == 0 && a->ldo % 4 == 0,
-                 "sd_conv1d_cl_split16_symmetric: needs x == w, M == cout, T == 1, a plain epilogue and 16-byte aligned output rows");
-    return launch_t256<float, true, true, true>(&k, vec, stream);
-  }
   if (plain) return launch_t256<float, true, true>(&k, vec, stream);
   return launch_t256<float, false, true>(&k, vec, stream);
 }

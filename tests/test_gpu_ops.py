@@ -178,29 +178,34 @@ def test_cosine_affinity_split16_matches_sklearn(dev, n, d):
     assert np.abs(blk - ref[lo:hi]).max() < 2e-6
 
 
-@pytest.mark.parametrize("n,pad", [(1504, 0), (2560, 0), (3000, 8), (3001, 0), (4104, 0), (8200, 8)])
+@pytest.mark.parametrize("n,pad", [(4, 0), (128, 0), (132, 4), (260, 0), (1500, 0), (1504, 0), (2052, 0), (2560, 0), (3000, 8), (3001, 0), (3004, 4),
+                                   (4104, 0), (8200, 8)])
 def test_cosine_affinity_split16_triangle_and_mirror(dev, n, pad):
-    """The split16x3 affinity of a whole matrix: 256 x 256 tiles on and above the diagonal, every off-diagonal tile stored a
-    second time transposed through LDS.  Every element must be there (partial edge tiles included), K exactly symmetric,
-    within the exact-f32 kernel's bar of sklearn, nothing written past a row; a size that is not a multiple of 8 takes the
-    every-tile path (same products, another summation order)."""
+    """The split16x3 affinity of a whole matrix (`sd_affinity.hip`): 128 x 128 tiles on and above the diagonal in 8 x 8 super-tiles, every
+    off-diagonal tile stored twice from the same accumulators (as it lies and quad-transposed), diagonal tiles element by element.
+    Every element must be there (partial edge tiles and partial super-tiles included), K exactly symmetric, within the exact-f32
+    kernel's bar of sklearn, nothing written past a row; a size that is not a multiple of 4 takes the every-tile path (same
+    products, another summation order)."""
     from sklearn.metrics.pairwise import cosine_similarity
     from speech_diarization_amd import ops
     rng = np.random.default_rng(n)
     x = rng.standard_normal((n, 192)).astype(np.float32) * rng.uniform(0.1, 10.0, size=(n, 1)).astype(np.float32)
-    x[11] = 0.0
+    if n > 11:
+        x[11] = 0.0
     xd = torch.from_numpy(x).to(dev)
     buf = torch.full((n, n + pad), float("nan"), device=dev)
     k = ops.cosine_affinity(xd, out=buf[:, :n], split16=True)
     assert not torch.isnan(k).any()
     if pad:
         assert torch.isnan(buf[:, n:]).all()
-    if n % 8 == 0:
+    if n % 4 == 0:
         assert torch.equal(k, k.T)
     ref = cosine_similarity(x.astype(np.float64))
     assert np.abs(k.cpu().numpy() - ref).max() < 2e-6
-    assert bool(torch.all(k[11] == 0)) and bool(torch.all(k[:, 11] == 0))
+    if n > 11:
+        assert bool(torch.all(k[11] == 0)) and bool(torch.all(k[:, 11] == 0))
     for lo, hi in ((0, 130), (n // 2 - 64, n // 2 + 200), (n - 131, n)):
+        lo, hi = max(lo, 0), min(hi, n)
         blk = ops.cosine_affinity(xd, rows=(lo, hi), split16=True)
         assert (blk - k[lo:hi]).abs().max() < 1e-6
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic (a --variant built with -DSD_STAMP): per-workgroup cycles of the split16x3 affinity's tiles
-(conv_gemm_f16_t256_kernel<SPLIT, SYM>): prologue / K loop / epilogue incl. the mirrored store, and the in-kernel clock.
+"""Diagnostic (a --variant built with -DSD_STAMP): per-workgroup cycles of the split16x3 affinity's 128 x 128 tiles
+(affinity_sym_split16_kernel, sd_affinity.hip): prologue / K loop / store issue / store drain, and the in-kernel clock.
 
     python speech-diarization_amd/build_native.py --variant stamp "-DSD_STAMP"
     SD_EXPERIMENT=1 SD_HIP_LIB=speech-diarization_amd/variants/libsd_hip_stamp.so python tools/stamp_affinity.py [N]
@@ -16,11 +16,12 @@ for _ in range(5):
     ops.cosine_affinity(x, out=K, split16=True)
 torch.cuda.synchronize()
 lib = _native.load(); m = 8192 * 8; buf = (C.c_ulonglong * m)()
-lib.sd_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
-assert lib.sd_debug_read_stamps(buf, m) == 0
+lib.sd_debug_read_affinity_stamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.sd_debug_read_affinity_stamps(buf, m) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.float64)
-nt = (n + 255) // 256; nb = min(8192, nt * (nt + 1) // 2); st = st[:nb]
-pro, loop, epi, tot, real = (np.median(st[:, i]) for i in range(5))
-clk = st[:, 3] / np.maximum(st[:, 4], 1) * 100.0
-print(f"N={n}: {nt * (nt + 1) // 2} tiles; per workgroup (wave 0, median of the first {nb}): prologue {pro:.0f}  K loop {loop:.0f} (6 steps; the matrix pipe "
-      f"needs 6 x 3072)  epilogue {epi:.0f}  total {tot:.0f} cycles = {tot / np.median(clk) :.1f} us at {np.median(clk):.0f} MHz")
+st = st[(st[:, 4] > 0) & (st[:, 6] == 1)]                      # stamped off-diagonal tiles
+pro, loop, issue, drain, tot = (np.median(st[:, i]) for i in range(5))
+clk = st[:, 4] / np.maximum(st[:, 5], 1) * 100.0
+print(f"N={n}: {len(st)} stamped off-diagonal tiles (every 16th workgroup), wave 0, medians: prologue {pro:.0f}  K loop {loop:.0f} (6 steps; the wave's "
+      f"MFMAs are 6 x 768)  epilogue shuffles + store issue {issue:.0f}  drain {drain:.0f}  total {tot:.0f} cycles = {tot / np.median(clk):.1f} us at {np.median(clk):.0f} MHz; "
+      f"p10 / p90 of the total {np.percentile(st[:, 4], 10):.0f} / {np.percentile(st[:, 4], 90):.0f}")

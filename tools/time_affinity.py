@@ -26,13 +26,13 @@ def main():
                 ops.cosine_affinity(x, out=K, **kw)
             torch.cuda.synchronize()
             t = []
-            for _ in range(5):
+            for _ in range(int(os.environ.get('REPS', '5'))):
                 t0 = time.perf_counter()
                 ops.cosine_affinity(x, out=K, **kw)
                 torch.cuda.synchronize()
                 t.append(time.perf_counter() - t0)
             dt = min(t)
-            rec[name] = {"ms": dt * 1e3, "write_tb_s": 4.0 * n * n / dt / 1e12}
+            rec[name] = {"ms": dt * 1e3, "write_tb_s": 4.0 * n * n / dt / 1e12, "all_ms": [round(v * 1e3, 3) for v in t]}
         out.append(rec)
     print(json.dumps({"sym": os.environ.get("SD_AFFINITY_SYM", "1"), "runs": out}))
 
