@@ -232,9 +232,14 @@ __global__ __launch_bounds__(256, 2) void affinity_sym_split16_kernel(const _Flo
   const _Float16* pb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+#ifdef SD_DIAG_SAME_PANELS       // timing-only diagnostic build: every tile loads rows 0 .. 255 (all L2 hits)
+    int m = r0 + 32 * i;
+    int n = 128 + r0 + 32 * i;
+#else
     int m = tile_m * AF_T + r0 + 32 * i;
-    m = m < N ? m : N - 1;
     int n = tile_n * AF_T + r0 + 32 * i;
+#endif
+    m = m < N ? m : N - 1;
     n = n < N ? n : N - 1;
     pa[i] = xs + (size_t)m * ldx + ls8;
     pb[i] = xs + (size_t)n * ldx + ls8;
