@@ -66,8 +66,8 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.pooled = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
   b.wpk_bytes = act_dtype == SD_DT_F16 ? sd_res2net_chain_workspace_bytes(w->res2_scale - 1) : 0;
   b.wpk = c.take(b.wpk_bytes, 1);
-  b.xs = (w->split16 && act_dtype == SD_DT_F32) ? c.take(M * (size_t)((Cm + 31) / 32 * 32), 4) : nullptr;
-  b.xcs = (w->split16 && act_dtype == SD_DT_F32 && Cm % 32 == 0 && C % 32 == 0) ? c.take(M * (size_t)Cm, 4) : nullptr;
+  b.xs = (w->split16 == 1 && act_dtype == SD_DT_F32) ? c.take(M * (size_t)((Cm + 31) / 32 * 32), 4) : nullptr;
+  b.xcs = (w->split16 == 1 && act_dtype == SD_DT_F32 && Cm % 32 == 0 && C % 32 == 0) ? c.take(M * (size_t)Cm, 4) : nullptr;
   b.a1 = b.x0;    // block-0 output is dead once block 1 has consumed it
   b.e = b.xcat;
   b.bytes = c.off;
@@ -194,7 +194,11 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   const int C = w->channels, Cm = w->mfa_channels, chunk = C / w->res2_scale;
   const int F32 = SD_DT_F32;
   const size_t es = dt == SD_DT_F16 ? 2 : 4;
-  const bool split = w->split16 != 0 && dt == SD_DT_F32;      // "f32-split16x3": wide layers on the f16 matrix cores, f32-level accuracy
+  // split16 = 1, "f32-split16x3": every frame-level contraction on the f16 matrix cores, three products per value pair, f32-level accuracy;
+  // split16 = 2: only the narrow layers (Res2Net convs, attention TDNN, the attention logits of the pooling kernel); the wide layers,
+  // 86 % of the flops, stay on the exact-f32 kernel
+  const bool split = w->split16 != 0 && dt == SD_DT_F32;
+  const bool wsplit = w->split16 == 1 && dt == SD_DT_F32;
 
   static const bool colstat_ok = [] {     // SD_COLSTAT=0: A/B switch for measurements
     const char* e = sd_experiment_env("SD_COLSTAT");
@@ -212,7 +216,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       x = b.t2; xdt = SD_DT_F16;
     }
     sd_conv_args a = conv_of(w->block0, x, xdt, w->n_mels, 0, b.x0, dt, C, 0, M, T, SD_ACT_RELU);
-    SD_TRY(run_wide(w->block0, a, split, b.xs, stream));
+    SD_TRY(run_wide(w->block0, a, wsplit, b.xs, stream));
   }
   const void* xin = b.x0; int ldin = C, colin = 0;
   for (int i = 0; i < w->n_blocks; ++i) {
@@ -231,7 +235,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       sd_conv_args a = conv_of(blk.tdnn1, xin, dt, ldin, colin, b.r, dt, C, 0, M, T, SD_ACT_RELU);
       if (!chain) { a.tee = b.s0; a.ldt = chunk; a.tee_lo = chunk; a.tee_hi = 2 * chunk; }
       // (blocks 2..: the input is a slice of xcat, whose split twin the previous block's SE kernel has written)
-      SD_TRY(run_wide(blk.tdnn1, a, split, b.xs, stream, (i > 0 && xin == b.xcat) ? b.xcs : nullptr, Cm));
+      SD_TRY(run_wide(blk.tdnn1, a, wsplit, b.xs, stream, (i > 0 && xin == b.xcat) ? b.xcs : nullptr, Cm));
     }
     if (chain) {
       SD_TRY(sd_res2net_chain_f16(b.r, C, B, T, blk.res2, w->res2_scale - 1, b.wpk, b.wpk_bytes, stream));
@@ -251,10 +255,10 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // geometry allows (the Res2Net scratch s0 is dead and holds them), else from a pass over t2
     {
       sd_conv_args a = conv_of(blk.tdnn2, b.r, dt, C, 0, b.t2, dt, C, 0, M, T, SD_ACT_RELU);
-      const bool stat = colstat_ok && T >= (split ? 128 : 64) && C % 256 == 0 && !(split && blk.tdnn2.w_split && wide_goes_narrow(blk.tdnn2, M)) &&
+      const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && C % 256 == 0 && !(wsplit && blk.tdnn2.w_split && wide_goes_narrow(blk.tdnn2, M)) &&
                         sd_colstat_floats(M, C) * sizeof(float) <= (size_t)M * chunk * es;
       if (stat) a.colstat = static_cast<float*>(b.s0);
-      SD_TRY(run_wide(blk.tdnn2, a, split, b.xs, stream));
+      SD_TRY(run_wide(blk.tdnn2, a, wsplit, b.xs, stream));
       if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
       else SD_TRY(sd_seg_mean_std_dt(b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
     }
@@ -267,17 +271,17 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     }
     // gate * t2 + shortcut -> slice i of the MFA input
     SD_TRY(sd_se_scale_residual_split(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, dt,
-                                      split ? b.xcs : nullptr, Cm, i * C, stream));
+                                      wsplit ? b.xcs : nullptr, Cm, i * C, stream));
     xin = b.xcat; ldin = Cm; colin = i * C;
   }
   // multi-layer feature aggregation; the global mean / std of attentive pooling likewise from the
   // epilogue (column sums in r, dead since the last block's tdnn2)
   {
     sd_conv_args a = conv_of(w->mfa, b.xcat, dt, Cm, 0, b.h, dt, Cm, 0, M, T, SD_ACT_RELU);
-    const bool stat = colstat_ok && T >= (split ? 128 : 64) && Cm % 256 == 0 && !(split && w->mfa.w_split && wide_goes_narrow(w->mfa, M)) &&
+    const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && Cm % 256 == 0 && !(wsplit && w->mfa.w_split && wide_goes_narrow(w->mfa, M)) &&
                       sd_colstat_floats(M, Cm) * sizeof(float) <= (size_t)M * C * es;
     if (stat) a.colstat = static_cast<float*>(b.r);
-    SD_TRY(run_wide(w->mfa, a, split, b.xs, stream, b.xcs, Cm));
+    SD_TRY(run_wide(w->mfa, a, wsplit, b.xs, stream, b.xcs, Cm));
     if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
     else SD_TRY(sd_seg_mean_std_dt(b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
   }

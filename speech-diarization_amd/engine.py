@@ -78,8 +78,8 @@ class EcapaWeights:
     """ECAPA-TDNN weights packed for the HIP kernels and resident on one device."""
 
     def __init__(self, state_dict: dict, device: torch.device, precision: str = "f32"):
-        if precision not in ("f32", "f16", "f32s"):
-            raise ValueError(f"precision must be 'f32', 'f16' or 'f32s' (f32-split16x3), got {precision!r}")
+        if precision not in ("f32", "f16", "f32s", "f32ns"):
+            raise ValueError(f"precision must be 'f32', 'f16', 'f32s' (f32-split16x3) or 'f32ns' (exact-f32 wide layers, split16x3 narrow ones), got {precision!r}")
         self.device = device
         self.precision = precision
         self.split_narrow = True      # f32s: also the narrow convs on the split kernel (False: wide layers only, as first built)
@@ -91,7 +91,7 @@ class EcapaWeights:
         sd = state_dict
         W = N.sd_ecapa_weights()
         W.w_dtype = N.SD_DT_F16 if precision == "f16" else N.SD_DT_F32
-        W.split16 = 1 if precision == "f32s" else 0
+        W.split16 = {"f32s": 1, "f32ns": 2}.get(precision, 0)      # 2: only the narrow layers carry the split packing
         W.n_mels = cfg.input_size
         W.channels = cfg.channels[0]
         W.n_blocks = cfg.n_blocks
@@ -156,8 +156,8 @@ class EcapaWeights:
         # the flops; 256x256 kernel, SD_DT_SPLIT16 activations) carry the weight scale 2^s in bias * 2^s / scale * 2^-s; narrow
         # ones (Res2Net convs, attention TDNN; 128x128 kernel that splits f32 activations while staging) pass 2^-s to the kernel
         L.w_split, L.bias_split, L.scale_split, L.split_scale_inv = None, None, None, 0.0
-        if self.precision == "f32s" and not per_segment and cin % 4 == 0:
-            if cout >= 1024 and affine is not None and bias is not None:
+        if self.precision in ("f32s", "f32ns") and not per_segment and cin % 4 == 0:
+            if self.precision == "f32s" and cout >= 1024 and affine is not None and bias is not None:
                 ws, s = pack_conv_weight_split16(w)
                 L.w_split = self._dev(ws, np.float16)
                 L.bias_split = self._dev(bias * np.float32(2.0 ** s))

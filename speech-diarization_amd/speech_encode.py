@@ -34,10 +34,11 @@ SYNTHETIC_SEED = 1234
 
 # Arithmetic of the ECAPA-TDNN forward behind `using_ecapa_encoder()`: "f32" (exact f32 MFMA, the reference CPU path's
 # arithmetic), "f32s" (f32-split16x3: f32 activations, the wide layers as three f16 MFMA products per value pair, f32-level
-# accuracy at twice the rate) or "f16" (f16 operands, f32 accumulation: BASELINE.json configs[4]).  A process-wide switch, like the
+# accuracy at twice the rate), "f32ns" (the wide layers on exact f32 MFMA, only the narrow Res2Net / attention convs as split products)
+# or "f16" (f16 operands, f32 accumulation: BASELINE.json configs[4]).  A process-wide switch, like the
 # reference's own precision knob (`torch.backends.cuda.matmul.allow_tf32 = True`, [REF diarization_baseline.py:20-21]);
 # initial value from the environment variable SD_ECAPA_PRECISION.
-_PRECISIONS = ("f32", "f32s", "f16")
+_PRECISIONS = ("f32", "f32s", "f32ns", "f16")
 _precision = os.environ.get("SD_ECAPA_PRECISION", "f32").lower()
 if _precision not in _PRECISIONS:
     raise ValueError(f"SD_ECAPA_PRECISION must be one of {_PRECISIONS}, got {_precision!r}")
@@ -48,7 +49,7 @@ def get_precision() -> str:
 
 
 def set_precision(precision: str) -> None:
-    """Select the arithmetic of the encoder singleton ("f32" | "f32s" | "f16"); drops the cached encoder so that the next
+    """Select the arithmetic of the encoder singleton ("f32" | "f32s" | "f32ns" | "f16"); drops the cached encoder so that the next
     `using_ecapa_encoder()` / `ecapa_encode_batch()` call builds one with the new setting."""
     global _precision
     if precision not in _PRECISIONS:

@@ -79,6 +79,11 @@ def test_precision_switch_reaches_the_drop_in_api(dev, tmp_path):
             es = speech_encode.ecapa_encode_batch(wav)
         assert speech_encode.using_ecapa_encoder().engine.precision == "f32s"
         assert not np.array_equal(es, e32) and _cos_dist(es, e32).max() < 1e-9
+        speech_encode.set_precision("f32ns")                     # exact-f32 wide layers, split16x3 narrow ones
+        with pytest.warns(RuntimeWarning):
+            en = speech_encode.ecapa_encode_batch(wav)
+        assert speech_encode.using_ecapa_encoder().engine.precision == "f32ns"
+        assert not np.array_equal(en, e32) and not np.array_equal(en, es) and _cos_dist(en, e32).max() < 1e-9
         with pytest.raises(ValueError):
             speech_encode.set_precision("bf16")
     finally:

@@ -196,6 +196,31 @@ def test_ecapa_split16_full_geometry_matches_oracle(dev, B, n):
     assert not np.array_equal(got, f32)                      # it IS another kernel
 
 
+@pytest.mark.parametrize("B,n", [(4, 32000), (3, 9600)])
+def test_ecapa_narrow_split_mode_matches_oracle(dev, B, n):
+    """precision "f32ns": the wide layers on the exact-f32 kernel, only the narrow convs and the attention logits as split16x3 products
+    (VERDICT r2 item 4's alternative).  The exact-f32 path's bars; another set of kernels than either "f32" or "f32s"; reachable
+    through the drop-in switch."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import speech_encode, synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    wav = synth.synthetic_segments(0, B, n)
+    wd = torch.from_numpy(wav).to(dev)
+    got = EmbeddingEngine(sd, dev, precision="f32ns").embed(wd).cpu().numpy()
+    f32 = EmbeddingEngine(sd, dev, precision="f32").embed(wd).cpu().numpy()
+    f32s = EmbeddingEngine(sd, dev, precision="f32s").embed(wd).cpu().numpy()
+    ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
+    cd = _cos_dist(got, ref)
+    print(f"\nf32 wide + split16x3 narrow vs float64: cos-dist {cd.max():.2e}, abs {np.abs(got - ref).max() / np.abs(ref).max():.2e} of max")
+    assert cd.max() < 1e-5, cd
+    assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max()
+    assert not np.array_equal(got, f32) and not np.array_equal(got, f32s)
+    assert "f32ns" in speech_encode._PRECISIONS
+    with pytest.raises(ValueError):
+        EmbeddingEngine(sd, dev, precision="f32x")
+
+
 def test_split16_identical_clusters_and_properties_at_full_size(dev):
     """north_star's 'identical cluster assignments' for the split16x3 engine (vs the exact-f32 engine and the CPU oracle,
     C = 1024), and the configs[1] batch (5000 segments through the 256x256 kernel at full occupancy): finite, run-to-run
