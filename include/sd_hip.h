@@ -281,8 +281,10 @@ typedef struct {
   int att_channels;   /* 128 */
   int emb_dim;        /* 192 */
   float asp_eps;      /* 1e-12 */
-  int split16;        /* != 0 (with w_dtype SD_DT_F32): layers that carry a w_split packing (the wide ones: stem, tdnn1,
-                         tdnn2, MFA) run on sd_conv1d_cl_split16 — the "f32-split16x3" mode; everything else stays exact f32 */
+  int split16;        /* with w_dtype SD_DT_F32.  1, the "f32-split16x3" mode: every frame-level layer that carries a w_split packing
+                         (wide: stem, tdnn1, tdnn2, MFA; narrow: Res2Net convs, attention TDNN) runs on sd_conv1d_cl_split16 and the
+                         fused pooling kernel forms its logits from split operands.  2: the narrow layers and the logits only — the
+                         wide layers (86 % of the flops) stay on the exact-f32 kernel.  0: exact f32 everywhere */
   sd_layer block0;
   sd_se_res2_block blocks[SD_MAX_BLOCKS];
   sd_layer mfa;
