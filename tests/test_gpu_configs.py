@@ -239,9 +239,11 @@ print("ok")
     assert res.returncode == 0 and res.stdout.strip().endswith("ok"), (res.stdout[-800:], res.stderr[-2500:])
 
 
-def test_config4_affinity_50k_properties(dev):
-    """50 000 x 50 000 f32 affinity (10 GB) in one call: unit diagonal, symmetry, bounded, planted
-    duplicates / zero rows, and agreement of a row block with the row-block entry point."""
+@pytest.mark.parametrize("split16", [False, True])
+def test_config4_affinity_50k_properties(dev, split16):
+    """50 000 x 50 000 f32 affinity (10 GB) in one call, exact f32 and the split16x3 kernel of configs[4] (`sd_affinity.hip`: EXACTLY
+    symmetric): unit diagonal, symmetry, bounded, planted duplicates / zero rows, and agreement of a row block with the row-block
+    entry point."""
     from speech_diarization_amd import ops
     n, d = 50000, 192
     g = torch.Generator(device=dev).manual_seed(7)
@@ -250,10 +252,10 @@ def test_config4_affinity_50k_properties(dev):
     x[40000] = 3.0 * x[17]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    K = ops.cosine_affinity(x)
+    K = ops.cosine_affinity(x, split16=split16)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"50k x 50k affinity: {dt * 1e3:.1f} ms, {4.0 * n * n / dt / 1e12:.2f} TB/s written, {384.0 * n * n / dt / 1e12:.1f} TFLOP/s")
+    print(f"50k x 50k affinity{' (split16x3)' if split16 else ''}: {dt * 1e3:.1f} ms, {4.0 * n * n / dt / 1e12:.2f} TB/s written, {384.0 * n * n / dt / 1e12:.1f} TFLOP/s")
     diag = torch.diagonal(K)
     keep = torch.ones(n, dtype=torch.bool, device=dev); keep[123] = False
     assert (diag[keep] - 1.0).abs().max() < 1e-5 and diag[123] == 0
@@ -262,10 +264,16 @@ def test_config4_affinity_50k_properties(dev):
     assert K.abs().max() <= 1.0 + 1e-5
     for lo in (0, 20000, 49000):                           # symmetry, checked block-wise to bound memory
         blk = K[lo:lo + 1000, :]
-        assert torch.equal(blk[:, lo:lo + 1000], blk[:, lo:lo + 1000].T) or (blk[:, lo:lo + 1000] - blk[:, lo:lo + 1000].T).abs().max() < 2e-7
-        assert (blk - K[:, lo:lo + 1000].T).abs().max() < 2e-7
-    rows = ops.cosine_affinity(x, rows=(31000, 31500))
-    assert torch.equal(rows, K[31000:31500])
+        assert torch.equal(blk[:, lo:lo + 1000], blk[:, lo:lo + 1000].T) or (not split16 and (blk[:, lo:lo + 1000] - blk[:, lo:lo + 1000].T).abs().max() < 2e-7)
+        if split16:
+            assert torch.equal(blk, K[:, lo:lo + 1000].T)      # one accumulator, two stores
+        else:
+            assert (blk - K[:, lo:lo + 1000].T).abs().max() < 2e-7
+    rows = ops.cosine_affinity(x, rows=(31000, 31500), split16=split16)
+    if split16:                                            # the row-block entry computes every tile: same products, another summation order
+        assert (rows - K[31000:31500]).abs().max() < 1e-6
+    else:
+        assert torch.equal(rows, K[31000:31500])
     sub = x[:2000].cpu().numpy()
     from sklearn.metrics.pairwise import cosine_similarity
     assert np.abs(K[:2000, :2000].cpu().numpy() - cosine_similarity(sub)).max() < 2e-6
