@@ -72,7 +72,12 @@ __device__ __forceinline__ float key_f32(int k) {
 constexpr int V2_XS_W = 5952;                       // per-wave sample image, floats (two spans + skew + alignment slack)
 constexpr int V2_STAGE_BYTES = 16 * 1024;           // basis fragments of one (pass, k step): 4 tiles x 4 kinds x 1 KB
 constexpr int V2_KSTEPS = 13;                       // 208 / 16
-constexpr int V2_LDS_BYTES = WAVES * V2_XS_W * 4 + 2 * V2_STAGE_BYTES;
+#ifndef SD_FB_PAIRED
+#define SD_FB_PAIRED 1           // 1: eight waves per workgroup, the two bin-tile passes of a 32-frame tile run CONCURRENTLY on a wave pair
+#endif                           //    that shares the tile's sample image (two waves per SIMD); 0: round 2's four waves, passes in sequence
+constexpr int V2_GROUPS = SD_FB_PAIRED ? 2 : 1;
+constexpr int V2_LDS_BYTES = WAVES * V2_XS_W * 4 + V2_GROUPS * 2 * V2_STAGE_BYTES;
+static_assert(V2_LDS_BYTES <= 160 * 1024, "sample images + basis stages must fit the CU's LDS");
 static_assert(WAVES * FT * MELP * 4 <= WAVES * V2_XS_W * 4, "the log-mel staging reuses the sample image");
 constexpr size_t V2_BASIS_BYTES = (size_t)V2_KSTEPS * NBT * 4 * 1024;        // 364 KB
 constexpr size_t V2_MELW_BYTES = (size_t)NBT * 2 * 3 * 2 * 1024;             // 84 KB
@@ -160,36 +165,50 @@ __device__ __forceinline__ void fbank2_pass(const Fbank2Args& p, const float* xs
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // next stage landed
     __syncthreads();                                                          // ... and everybody is done with this one
   }
-  // ---- |X|^2 -> mel: accumulator registers 8 s2 .. 8 s2 + 7 are the B fragment of k half s2 (rows = bins = k)
+  // ---- |X|^2 -> mel: accumulator registers 8 s2 .. 8 s2 + 7 are the B fragment of k half s2 (rows = bins = k).
+  // The mel weights come straight from global memory (84 KB, L2-resident); the six fragments of step it + 1 are requested in front of
+  // step it's MFMAs (round 3 stamps: with the loads issued where they were used, pass 0's mel stage cost 20.9 k cycles, a dependent
+  // L2 round trip per fragment, against 3.6 k for pass 1, whose lines the first pass had pulled in)
+  bf8v wcur[6], wnxt[6];
+  auto wload = [&](bf8v (&w)[6], int it) {
+    const __bf16* wq = p.melw + ((size_t)(Q0 + it / 2) * 2 * 3 * 2 * 64 + lane) * 8;
+    const int s2 = it & 1;
 #pragma unroll
-  for (int q = 0; q < NTILE; ++q) {
-    const __bf16* wq = p.melw + ((size_t)(Q0 + q) * 2 * 3 * 2 * 64 + lane) * 8;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf8v p1, p2;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float pw = (re[q][8 * s2 + e] * re[q][8 * s2 + e] + im[q][8 * s2 + e] * im[q][8 * s2 + e]) * (1.0f / (SD_FB_SCALE * SD_FB_SCALE));
-        p1[e] = (__bf16)pw;
-        p2[e] = (__bf16)(pw - (float)p1[e]);
-      }
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const bf8v w1 = *reinterpret_cast<const bf8v*>(wq + ((size_t)(s2 * 3 + t) * 2 + 0) * 64 * 8);
-        const bf8v w2 = *reinterpret_cast<const bf8v*>(wq + ((size_t)(s2 * 3 + t) * 2 + 1) * 64 * 8);
-        mel[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, mel[t], 0, 0, 0);
-        mel[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p2, mel[t], 0, 0, 0);
-        mel[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, p1, mel[t], 0, 0, 0);
-      }
+    for (int t = 0; t < 3; ++t) {
+      w[2 * t] = *reinterpret_cast<const bf8v*>(wq + ((size_t)(s2 * 3 + t) * 2 + 0) * 64 * 8);
+      w[2 * t + 1] = *reinterpret_cast<const bf8v*>(wq + ((size_t)(s2 * 3 + t) * 2 + 1) * 64 * 8);
     }
+  };
+  wload(wcur, 0);
+#pragma unroll
+  for (int it = 0; it < 2 * NTILE; ++it) {
+    const int q = it / 2, s2 = it & 1;
+    if (it + 1 < 2 * NTILE) wload(wnxt, it + 1);
+    bf8v p1, p2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float pw = (re[q][8 * s2 + e] * re[q][8 * s2 + e] + im[q][8 * s2 + e] * im[q][8 * s2 + e]) * (1.0f / (SD_FB_SCALE * SD_FB_SCALE));
+      p1[e] = (__bf16)pw;
+      p2[e] = (__bf16)(pw - (float)p1[e]);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      mel[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wcur[2 * t], p1, mel[t], 0, 0, 0);
+      mel[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wcur[2 * t], p2, mel[t], 0, 0, 0);
+      mel[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wcur[2 * t + 1], p1, mel[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wcur[i] = wnxt[i];
   }
 }
 
-__global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const Fbank2Args p) {
+__global__ __launch_bounds__(256 * V2_GROUPS, 1) void fbank_logmel_kernel(const Fbank2Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = (tid >> 6) & 3;                     // which of the workgroup's four 32-frame tiles
+  const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);   // paired build: 0 = bin tiles 0-3, 1 = bin tiles 4-6 of the SAME tile (same SIMD)
   float* xs = smem + wid * V2_XS_W;
-  char* stage = reinterpret_cast<char*>(smem + WAVES * V2_XS_W);
+  char* stage = reinterpret_cast<char*>(smem + WAVES * V2_XS_W) + grp * 2 * V2_STAGE_BYTES;
   float* macc = smem + wid * FT * MELP;               // after the DFT: [frame][mel] staging in the (dead) sample image
 
   // ---- which frames does this wave own (all wave-uniform)
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const Fbank2Args p
     constexpr int SB = 32;
     auto stage_span = [&](int b, int s0, int len, int off) {
       const long long start = p.starts ? p.starts[b] : (long long)b * p.n;      // first sample of row b in `wav`
-      for (int rel0 = lane; rel0 < len; rel0 += 64 * SB) {
+      for (int rel0 = lane + grp * 64 * SB; rel0 < len; rel0 += V2_GROUPS * 64 * SB) {     // (the pair stages alternate batches)
         float v[SB];
         bool okv[SB];
 #pragma unroll
@@ -279,6 +298,28 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const Fbank2Args p
   for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) mel[t][r] = 0.f;
+#if SD_FB_PAIRED
+  // both passes at once: the two waves of a pair sit on the same SIMD, so one's fragment building, LDS reads and barrier waits
+  // run under the other's MFMAs (stamps of the sequential form: a k step took 2100-2900 cycles for 576-768 of matrix work).
+  // Same number of barriers in both branches (1 + 13 each).
+  if (grp == 0) fbank2_pass<4, 0>(p, xs, base, stage, lane, wid, mel);
+  else fbank2_pass<3, 4>(p, xs, base, stage, lane, wid, mel);
+  __syncthreads();                                    // every wave is done with its sample image
+  // the pair's partial mel sums (bins of tiles 0-3 / 4-6) meet in LDS [frame][mel]
+#pragma unroll 1
+  for (int g = 0; g < 2; ++g) {
+    if (grp == g) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < p.n_mels) macc[j * MELP + m] = g == 0 ? mel[t][r] : macc[j * MELP + m] + mel[t][r];
+        }
+    }
+    __syncthreads();
+  }
+#else
   fbank2_pass<4, 0>(p, xs, base, stage, lane, wid, mel);
   fbank2_pass<3, 4>(p, xs, base, stage, lane, wid, mel);
   __syncthreads();                                    // every wave is done with its sample image
@@ -292,9 +333,11 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const Fbank2Args p
       if (m < p.n_mels) macc[j * MELP + m] = mel[t][r];
     }
   __syncthreads();
+#endif
   {
-    const int mh = (p.n_mels + 1) / 2;
-    const int m_lo = h * mh;
+    // a frame's mels are shared by the lane pair (j, h) and, in the paired build, by the two waves of the tile
+    const int mh = (p.n_mels + 2 * V2_GROUPS - 1) / (2 * V2_GROUPS);
+    const int m_lo = (grp * 2 + h) * mh < p.n_mels ? (grp * 2 + h) * mh : p.n_mels;
     const int m_hi = (m_lo + mh < p.n_mels) ? m_lo + mh : p.n_mels;
     float vmax = -INFINITY;
     float* mrow = macc + j * MELP;
@@ -320,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void fbank_logmel_kernel(const Fbank2Args p
   {
     const int total = nvalid * p.n_mels;
     float* const orow = p.out + (size_t)rowA * p.ld_out;
-    for (int e = lane; e < total; e += 64) {
+    for (int e = lane + 64 * grp; e < total; e += 64 * V2_GROUPS) {
       const int jj = (int)__umulhi((unsigned)e, p.inv_mels);                  // e / n_mels (exact for e < 2^16: inv_mels = ceil(2^32 / n_mels))
       const int m = e - jj * p.n_mels;
       orow[(size_t)jj * p.ld_out + m] = macc[jj * MELP + m];
@@ -532,7 +575,7 @@ static int fbank_launch(const sd_fbank_plan* plan, const float* wav_dev, long lo
   {
     // algorithmic bytes: waveform read once + log-mel written once (192 320 B per 2 s segment)
     SdProfScope prof(SD_PROF_FBANK, stream, (double)B * ((double)n * 4.0 + (double)T * plan->n_mels * 4.0));
-    hipLaunchKernelGGL(fbank_logmel_kernel, dim3((unsigned)blocks), dim3(256), V2_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(fbank_logmel_kernel, dim3((unsigned)blocks), dim3(256 * V2_GROUPS), V2_LDS_BYTES, stream, a);
   }
   SD_CHECK_LAUNCH("fbank_logmel_kernel");
   const int use_floor = plan->log_mode == SD_LOG_DB_TOPDB && plan->top_db >= 0.f;
