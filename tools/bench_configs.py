@@ -127,9 +127,9 @@ def main():
         torch.cuda.synchronize()
         t.append(time.perf_counter() - t0)
     dt = min(t)
-    out["micro_batch_sweep"] = {p: micro_batch_sweep(sd, dev, p) for p in ("f32", "f16", "f32s")}
+    out["micro_batch_sweep"] = {p: micro_batch_sweep(sd, dev, p) for p in ("f32", "f32ns", "f32s", "f16")}
     out["reassignment_windows_1h"] = [reassignment_windows(sd, dev, p) for p in ("f32", "f32s", "f16")]
-    out["host_api_numpy_in_out"] = [host_api_rate(b, n, precision=p) for p in ("f32", "f32s", "f16") for b, n in ((32, 32000), (128, 32000), (128, 16000))]
+    out["host_api_numpy_in_out"] = [host_api_rate(b, n, precision=p) for p in ("f32", "f32ns", "f32s", "f16") for b, n in ((32, 32000), (128, 32000), (128, 16000))]
     out["affinity_50k"] = {"ms": dt * 1e3, "tflops": 384.0 * 50000 ** 2 / dt / 1e12, "write_tb_s": 4.0 * 50000 ** 2 / dt / 1e12}
     ops.cosine_affinity(x, out=K, split16=True)
     torch.cuda.synchronize()
