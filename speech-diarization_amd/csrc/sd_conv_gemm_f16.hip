@@ -821,6 +821,219 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// EXPERIMENT, compiled only into variant builds (build_native.py --variant w4 "-DSD_WITH_W4", selected at run time with
+// SD_EXPERIMENT=1 SD_F16_W4=1): the same 256x256 tile and LDS-DMA ring with FOUR waves of 128 x 128.  A K step's
+// fragment reads drop from 8 x 24 KB to 4 x 32 KB (the 8-wave form moves 192 KB of reads + 64 KB of DMA writes per step through a
+// 128 B/clk LDS for 2048 cycles of matrix work), at the price of one wave per SIMD: its 256 accumulator registers live in AGPRs
+// (200 VGPRs + 256 AGPRs, no spill, no v_accvgpr copy in the loop), nothing hides a stall but the wave's own instruction stream.
+// f16 operands, register (DIRECT) epilogue only.  Per step and wave: 128 MFMAs, 32 ds_read_b128 in two sets of 64 registers
+// (k slice 0 / 1), 16 DMA pieces (the weights of step k + 1, the activations of step k + 2); the barrier sits in front of the
+// step's LAST 64 MFMAs.  The loop body is straight-line and pinned chunk by chunk with sched_barrier (ISA: MMMMMMMM RRR D x 16 per
+// step, two waits, one barrier).  Passes tests/test_gpu_f16.py (158 tests).  Measured against the shipped 8-wave kernel, same box,
+// 1 005 000 rows: 1024 x 1024 871-873 vs 900-912 TFLOP/s, 3072 x 3072 1147-1149 vs 1120-1121 (first cut, compiler-scheduled: 858 /
+// 1159 vs 898 / 1151).  Not shipped: a wave that is alone on its SIMD stands still whenever one of its 16 DMA pieces waits for a
+// slot in the CU's vector-memory queue (round 2: 70-100 cycles per piece with four waves issuing), and with 456 registers per wave
+// there is no room for loader waves beside it.
+#ifdef SD_WITH_W4
+template <typename TO>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_gemm_f16_w4_kernel(const sd_conv_args p, const int vec) {
+  constexpr int TBK = 64;
+  constexpr int TROW = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int n_tiles = (p.cout + TBN - 1) / TBN;
+  int wg;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_n = wg % n_tiles, tile_m = wg / n_tiles;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+
+  // staging role: thread (r0 = tid / 8, ps = tid % 8) fills physical 16-byte slot ps of rows r0 + 32 i (i < 8) of BOTH operands.
+  // Addresses = a workgroup-uniform base (SGPRs) + a 32-bit per-lane element offset: 16 address registers instead of 32.
+  const int r0 = tid >> 3;
+  const int ls8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;
+  const int ktot = p.taps * p.cin_pad;
+  const int nk = p.taps * (p.cin_pad / TBK);
+  const int half = p.taps / 2;
+  int m0c = m0 < p.M ? m0 : p.M - 1;
+  const _Float16* const Ab = static_cast<const _Float16*>(p.x) + p.a_col0 + (size_t)m0c * p.lda;      // row m0 of the activations
+  int n0c = n0 < p.cout ? n0 : p.cout - 1;
+  const _Float16* Wb = static_cast<const _Float16*>(p.w) + (size_t)n0c * ktot;                        // row n0 of the weights, advanced per K step
+  int pa[8], pb[8];
+  auto set_tap = [&](int tap) {
+    const int delta = (tap - half) * p.dil;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int m = m0 + r0 + 32 * i;
+      m = m < p.M ? m : p.M - 1;
+      const int seg = (m / p.T) * p.T;
+      int tt = m - seg + delta;
+      tt = tt < 0 ? -tt : tt;
+      tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
+      pa[i] = (seg + tt - m0c) * p.lda;                 // |rows| < 256 + T: fits 32 bits for any lda this library accepts
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int n = n0 + r0 + 32 * i;
+    n = n < p.cout ? n : p.cout - 1;
+    pb[i] = (n - n0c) * ktot + ls8;
+  }
+  set_tap(0);
+  int ld_tap = 0, ld_c0 = 0;
+  char* const dst = smem_raw + (wid * 8) * TROW;
+  auto issue_b = [&](int st) {
+    char* base = dst + R3_B_BASE + st * R3_B_STAGE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) SD_GLDS16(Wb + pb[i], base + i * 32 * TROW);
+    Wb += TBK;
+  };
+  auto issue_a = [&](int st) {
+    char* base = dst + st * R3_A_STAGE;
+    const int col = ld_c0 + ls8;
+    const int acol = col < p.cin ? col : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) SD_GLDS16(Ab + (pa[i] + acol), base + i * 32 * TROW);
+    ld_c0 += TBK;
+    if (ld_c0 >= p.cin_pad) {
+      ld_c0 = 0;
+      ++ld_tap;
+      if (ld_tap < p.taps) set_tap(ld_tap);
+    }
+  };
+
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v acc0[8][4], acc1[8][4];          // [16-row time tile][16-channel tile]: channels 0-63 / 64-127 of the wave's 128
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ab_sw = (fr >> 1) & 7;
+  const char* const a_base = smem_raw + (wm * 128 + fr) * TROW;
+  const char* const b_base = smem_raw + R3_B_BASE + (wn * 128 + fr) * TROW;
+  const int so0 = (fq ^ ab_sw) << 4, so1 = ((4 + fq) ^ ab_sw) << 4;
+
+  h8 xa[8], xb[8], ya[8], yb[8];          // fragment sets of k slice 0 (x) and 1 (y)
+#define W4_READ(fa_, fb_, sa_, sb_, so_)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                 \
+    fa_[i] = *reinterpret_cast<const h8*>(a_base + (sa_) * R3_A_STAGE + i * 16 * TROW + (so_));                   \
+    fb_[i] = *reinterpret_cast<const h8*>(b_base + (sb_) * R3_B_STAGE + i * 16 * TROW + (so_));                   \
+  }
+#define W4_MMA(fa_, fb_)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+      acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[j], fa_[i], acc0[i][j], 0, 0, 0);                   \
+      acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[4 + j], fa_[i], acc1[i][j], 0, 0, 0);               \
+    }                                                                                                             \
+  }
+
+  issue_b(0);
+  issue_a(0);
+  if (nk > 1) issue_a(1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ya[i][e] = (_Float16)0.f; yb[i][e] = (_Float16)0.f; }     // the first step's "deferred" slice adds zeros
+  int sa = 0, sb = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- barrier(kt): this step's stages have landed, every wave holds the previous step's last fragments in registers
+    if (kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");        // the activations of step kt + 1 stay in flight
+    __builtin_amdgcn_s_barrier();
+    const int sa2 = sa == 0 ? 2 : sa - 1;                                    // the A stage of step kt - 1
+    // One straight-line body, instruction order pinned chunk by chunk (left to itself hipcc sinks the 16 fragment reads of a half
+    // step behind ~58 of the 64 MFMAs they should run under and waits for them right after): a chunk = the two fragment reads of row
+    // tile i of the NEXT k slice, one DMA piece, and the 8 MFMAs of row tile i of the slice whose fragments are complete.  Past the
+    // last step the DMA pieces are re-reads of valid addresses into stages nobody reads (no branch in the body).
+    const bool hb = kt + 1 < nk, ha = kt + 2 < nk;
+    const char* const ar = a_base + sa * R3_A_STAGE;
+    const char* const br = b_base + sb * R3_B_STAGE;
+    char* const bdst = dst + R3_B_BASE + (sb ^ 1) * R3_B_STAGE;
+    char* const adst = dst + sa2 * R3_A_STAGE;
+    const int col = ld_c0 + ls8;
+    const int acol = (ha && col < p.cin) ? col : 0;
+    const _Float16* const Wk = hb ? Wb : Wb - TBK;
+    // chunk i = the 8 MFMAs of row tile i, then (chunks 0-5 only) fragment reads of the next slice: 3, 3, 3, 3, 2, 2 — the last two
+    // chunks' MFMAs cover the latency of the last reads, so the next half step starts without a wait
+#define W4_Q(k_) ((k_) < 8 ? 8 + (k_) : (k_) - 8)          /* k-th fragment read: all 8 b, then a[0..7], the order the consumer needs them */
+#define W4_RD(fa_, fb_, q_, so_)                                                                              \
+  do {                                                                                                       \
+    if ((q_) < 8) fa_[(q_)] = *reinterpret_cast<const h8*>(ar + (q_) * 16 * TROW + (so_));                    \
+    else fb_[(q_) - 8] = *reinterpret_cast<const h8*>(br + ((q_) - 8) * 16 * TROW + (so_));                   \
+  } while (0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                                            // deferred k slice 1 of step kt - 1
+        acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yb[j], ya[i], acc0[i][j], 0, 0, 0);
+        acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yb[4 + j], ya[i], acc1[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i < 4) { W4_RD(xa, xb, W4_Q(3 * i), so0); W4_RD(xa, xb, W4_Q(3 * i + 1), so0); W4_RD(xa, xb, W4_Q(3 * i + 2), so0); }
+      else if (i < 6) { W4_RD(xa, xb, W4_Q(12 + 2 * (i - 4)), so0); W4_RD(xa, xb, W4_Q(13 + 2 * (i - 4)), so0); }
+      SD_GLDS16(Wk + pb[i], bdst + i * 32 * TROW);                             // the weights of step kt + 1
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[j], xa[i], acc0[i][j], 0, 0, 0);
+        acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[4 + j], xa[i], acc1[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i < 4) { W4_RD(ya, yb, W4_Q(3 * i), so1); W4_RD(ya, yb, W4_Q(3 * i + 1), so1); W4_RD(ya, yb, W4_Q(3 * i + 2), so1); }
+      else if (i < 6) { W4_RD(ya, yb, W4_Q(12 + 2 * (i - 4)), so1); W4_RD(ya, yb, W4_Q(13 + 2 * (i - 4)), so1); }
+      SD_GLDS16(Ab + (pa[i] + acol), adst + i * 32 * TROW);                    // the activations of step kt + 2
+    }
+#undef W4_RD
+#undef W4_Q
+    __builtin_amdgcn_sched_barrier(0);
+    if (hb) Wb += TBK;
+    if (ha) {
+      ld_c0 += TBK;
+      if (ld_c0 >= p.cin_pad) {
+        ld_c0 = 0;
+        ++ld_tap;
+        if (ld_tap < p.taps) set_tap(ld_tap);
+      }
+    }
+    sa = sa == 2 ? 0 : sa + 1;
+    sb ^= 1;
+  }
+  W4_MMA(ya, yb);
+#undef W4_READ
+#undef W4_MMA
+  sd_direct_epilogue<TO>(p, acc0, m0 + wm * 128, n0 + wn * 128, fr, fq);
+  sd_direct_epilogue<TO>(p, acc1, m0 + wm * 128, n0 + wn * 128 + 64, fr, fq);
+}
+
+template <typename TO>
+int launch_w4(const sd_conv_args* a, int vec, hipStream_t stream) {
+  const long tiles_m = (a->M + TBM - 1) / TBM;
+  const long tiles_n = (a->cout + TBN - 1) / TBN;
+  auto kern = conv_gemm_f16_w4_kernel<TO>;
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), R3_LDS_BYTES));
+  {
+    SdProfScope prof(SD_PROF_CONV_WIDE, stream, 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), R3_LDS_BYTES, stream, *a, vec);
+  }
+  SD_CHECK_LAUNCH("conv_gemm_f16_w4_kernel");
+  return SD_OK;
+}
+#endif  // SD_WITH_W4
+
 template <typename TO, bool DIRECT, bool SPLIT = false>
 int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
   const long tiles_m = (a->M + TBM - 1) / TBM;
@@ -926,6 +1139,10 @@ extern "C" int sd_conv1d_cl_f16(const sd_conv_args* a, sd_stream_t stream_) {
       return !(e && e[0] == '0');
     }();
     const bool plain = vec && (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg && !a->tee;
+#ifdef SD_WITH_W4
+    static const bool w4 = [] { const char* e = sd_experiment_env("SD_F16_W4"); return e && e[0] == '1'; }();     // A/B: the 4-wave form
+    if (plain && direct_ok && w4) return ya ? launch_w4<_Float16>(a, vec, stream) : launch_w4<float>(a, vec, stream);
+#endif
     if (plain && direct_ok) return ya ? launch_t256<_Float16, true>(a, vec, stream) : launch_t256<float, true>(a, vec, stream);
     return ya ? launch_t256<_Float16, false>(a, vec, stream) : launch_t256<float, false>(a, vec, stream);
   }
