@@ -325,6 +325,7 @@ int sd_affinity_sym_split16(const void* xs, int ldx, int N, int groups, float* o
   const int nsup = (nt + AF_SUP - 1) / AF_SUP;
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(affinity_sym_split16_kernel), AF_LDS));
   const long nwg = (long)nsup * (nsup + 1) / 2 * (AF_SUP * AF_SUP);
+  if (nwg >= (1L << 31)) return sd_set_error(SD_ERR_ARG, "sd_affinity_sym_split16: N=%d needs %ld workgroups", N, nwg);
   hipLaunchKernelGGL(affinity_sym_split16_kernel, dim3((unsigned)nwg), dim3(256), AF_LDS, static_cast<hipStream_t>(stream),
                      static_cast<const _Float16*>(xs), ldx, N, groups, out, ldo, alpha, nt, nsup);
   SD_CHECK_LAUNCH("affinity_sym_split16_kernel");
