@@ -72,11 +72,28 @@ __device__ __forceinline__ float key_f32(int k) {
 constexpr int V2_XS_W = 5952;                       // per-wave sample image, floats (two spans + skew + alignment slack)
 constexpr int V2_STAGE_BYTES = 16 * 1024;           // basis fragments of one (pass, k step): 4 tiles x 4 kinds x 1 KB
 constexpr int V2_KSTEPS = 13;                       // 208 / 16
-#ifndef SD_FB_PAIRED
-#define SD_FB_PAIRED 1           // 1: eight waves per workgroup, the two bin-tile passes of a 32-frame tile run CONCURRENTLY on a wave pair
-#endif                           //    that shares the tile's sample image (two waves per SIMD); 0: round 2's four waves, passes in sequence
-constexpr int V2_GROUPS = SD_FB_PAIRED ? 2 : 1;
-constexpr int V2_LDS_BYTES = WAVES * V2_XS_W * 4 + V2_GROUPS * 2 * V2_STAGE_BYTES;
+#ifndef SD_FB_GROUPS
+#define SD_FB_GROUPS 2           // wave groups per workgroup: the 7 bin tiles of a 32-frame tile are split 4 + 3 over TWO waves on the same SIMD
+#endif                           // that share the tile's sample image.  3: 3 + 2 + 2 over three waves (measured: 1.369 vs 1.358 ms, no gain over
+                                 // two); 1: round 2's four waves, two passes in sequence (1.61 ms)
+constexpr int V2_GROUPS = SD_FB_GROUPS;
+static_assert(V2_GROUPS >= 1 && V2_GROUPS <= 3, "");
+// bin tiles [G_Q0, G_Q0 + G_NT) of group g (SD_FB_GROUPS = 1 keeps the 4 + 3 split as two sequential passes)
+__host__ __device__ constexpr int fb_nt(int g) { return V2_GROUPS == 3 ? (g == 0 ? 3 : 2) : (g == 0 ? 4 : 3); }
+__host__ __device__ constexpr int fb_q0(int g) { return V2_GROUPS == 3 ? (g == 0 ? 0 : (g == 1 ? 3 : 5)) : (g == 0 ? 0 : 4); }
+constexpr int V2_NPASS = V2_GROUPS == 1 ? 2 : V2_GROUPS;                     // basis blocks are packed per pass
+__host__ __device__ constexpr size_t fb_basis_off(int g) {                    // bytes in front of pass g's blocks
+  size_t o = 0;
+  for (int i = 0; i < g; ++i) o += (size_t)13 * fb_nt(i) * 4 * 1024;
+  return o;
+}
+__host__ __device__ constexpr int fb_ring_off(int g) {                        // bytes in front of group g's two-stage ring in LDS
+  int o = 0;
+  for (int i = 0; i < g; ++i) o += 2 * fb_nt(i) * 4 * 1024;
+  return o;
+}
+constexpr int V2_RING_BYTES = V2_GROUPS == 1 ? 2 * V2_STAGE_BYTES : fb_ring_off(V2_GROUPS);
+constexpr int V2_LDS_BYTES = WAVES * V2_XS_W * 4 + V2_RING_BYTES;
 static_assert(V2_LDS_BYTES <= 160 * 1024, "sample images + basis stages must fit the CU's LDS");
 static_assert(WAVES * FT * MELP * 4 <= WAVES * V2_XS_W * 4, "the log-mel staging reuses the sample image");
 constexpr size_t V2_BASIS_BYTES = (size_t)V2_KSTEPS * NBT * 4 * 1024;        // 364 KB
@@ -103,7 +120,7 @@ struct Fbank2Args {
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 // one pass over NTILE bin tiles starting at tile Q0: DFT into acc, then their power spectra into the mel accumulators
-template <int NTILE, int Q0>
+template <int NTILE, int Q0, int PASS, bool ZERO_MEL>
 __device__ __forceinline__ void fbank2_pass(const Fbank2Args& p, const float* xs, int base, char* stage, int lane, int wid,
                                             f32x16 (&mel)[3]) {
   const int j = lane & 31, h = lane >> 5;
@@ -114,12 +131,12 @@ __device__ __forceinline__ void fbank2_pass(const Fbank2Args& p, const float* xs
 #pragma unroll
     for (int r = 0; r < 16; ++r) { re[q][r] = 0.f; im[q][r] = 0.f; }
   constexpr int STAGE = NTILE * 4 * 1024;                                     // bytes of one (pass, k step) block
-  const char* const gsrc = reinterpret_cast<const char*>(p.basis) + (Q0 == 0 ? 0 : (size_t)V2_KSTEPS * 4 * 4 * 1024);
+  const char* const gsrc = reinterpret_cast<const char*>(p.basis) + fb_basis_off(PASS);
   auto dma = [&](int s, int buf) {                                            // wave w moves pieces w, w + 4, ...
 #pragma unroll
     for (int pc = 0; pc < NTILE; ++pc) {
       const int piece = pc * WAVES + wid;
-      FB2_GLDS16(gsrc + (size_t)s * STAGE + piece * 1024 + lane * 16, stage + buf * V2_STAGE_BYTES + piece * 1024);
+      FB2_GLDS16(gsrc + (size_t)s * STAGE + piece * 1024 + lane * 16, stage + buf * STAGE + piece * 1024);
     }
   };
   dma(0, 0);
@@ -148,7 +165,7 @@ __device__ __forceinline__ void fbank2_pass(const Fbank2Args& p, const float* xs
       ahi[e] = (_Float16)a; alo[e] = (_Float16)(a - (float)ahi[e]);
       dhi[e] = (_Float16)d; dlo[e] = (_Float16)(d - (float)dhi[e]);
     }
-    const char* st = stage + (s & 1) * V2_STAGE_BYTES + lane * 16;
+    const char* st = stage + (s & 1) * STAGE + lane * 16;
 #pragma unroll
     for (int q = 0; q < NTILE; ++q) {
       const h8v chi = *reinterpret_cast<const h8v*>(st + (q * 4 + 0) * 1024);
@@ -169,6 +186,12 @@ __device__ __forceinline__ void fbank2_pass(const Fbank2Args& p, const float* xs
   // The mel weights come straight from global memory (84 KB, L2-resident); the six fragments of step it + 1 are requested in front of
   // step it's MFMAs (round 3 stamps: with the loads issued where they were used, pass 0's mel stage cost 20.9 k cycles, a dependent
   // L2 round trip per fragment, against 3.6 k for pass 1, whose lines the first pass had pulled in)
+  if (ZERO_MEL) {                                                             // (a wave that runs ONE pass: the mel accumulators need not live through the k loop)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mel[t][r] = 0.f;
+  }
   bf8v wcur[6], wnxt[6];
   auto wload = [&](bf8v (&w)[6], int it) {
     const __bf16* wq = p.melw + ((size_t)(Q0 + it / 2) * 2 * 3 * 2 * 64 + lane) * 8;
@@ -206,9 +229,9 @@ __global__ __launch_bounds__(256 * V2_GROUPS, 1) void fbank_logmel_kernel(const 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = (tid >> 6) & 3;                     // which of the workgroup's four 32-frame tiles
-  const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);   // paired build: 0 = bin tiles 0-3, 1 = bin tiles 4-6 of the SAME tile (same SIMD)
+  const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);   // which share of the tile's 7 bin tiles (waves w, w + 4, w + 8 sit on the same SIMD)
   float* xs = smem + wid * V2_XS_W;
-  char* stage = reinterpret_cast<char*>(smem + WAVES * V2_XS_W) + grp * 2 * V2_STAGE_BYTES;
+  char* stage = reinterpret_cast<char*>(smem + WAVES * V2_XS_W) + (V2_GROUPS == 1 ? 0 : (grp == 0 ? fb_ring_off(0) : grp == 1 ? fb_ring_off(1) : fb_ring_off(2)));
   float* macc = smem + wid * FT * MELP;               // after the DFT: [frame][mel] staging in the (dead) sample image
 
   // ---- which frames does this wave own (all wave-uniform)
@@ -294,20 +317,19 @@ __global__ __launch_bounds__(256 * V2_GROUPS, 1) void fbank_logmel_kernel(const 
   __syncthreads();
 
   f32x16 mel[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mel[t][r] = 0.f;
-#if SD_FB_PAIRED
-  // both passes at once: the two waves of a pair sit on the same SIMD, so one's fragment building, LDS reads and barrier waits
-  // run under the other's MFMAs (stamps of the sequential form: a k step took 2100-2900 cycles for 576-768 of matrix work).
-  // Same number of barriers in both branches (1 + 13 each).
-  if (grp == 0) fbank2_pass<4, 0>(p, xs, base, stage, lane, wid, mel);
-  else fbank2_pass<3, 4>(p, xs, base, stage, lane, wid, mel);
+#if SD_FB_GROUPS > 1
+  // every share of the bin tiles at once: the waves of a tile sit on the same SIMD, so one's fragment building, LDS reads and barrier
+  // waits run under the others' MFMAs (stamps of the sequential form: a k step took 2100-2900 cycles for 576-768 of matrix work).
+  // Same number of barriers in every branch (1 + 13 each).
+  if (grp == 0) fbank2_pass<fb_nt(0), fb_q0(0), 0, true>(p, xs, base, stage, lane, wid, mel);
+  else if (grp == 1) fbank2_pass<fb_nt(1), fb_q0(1), 1, true>(p, xs, base, stage, lane, wid, mel);
+#if SD_FB_GROUPS > 2
+  else fbank2_pass<fb_nt(2), fb_q0(2), 2, true>(p, xs, base, stage, lane, wid, mel);
+#endif
   __syncthreads();                                    // every wave is done with its sample image
-  // the pair's partial mel sums (bins of tiles 0-3 / 4-6) meet in LDS [frame][mel]
+  // the partial mel sums of the tile's waves meet in LDS [frame][mel], in group order (deterministic)
 #pragma unroll 1
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < V2_GROUPS; ++g) {
     if (grp == g) {
 #pragma unroll
       for (int t = 0; t < 3; ++t)
@@ -320,8 +342,12 @@ __global__ __launch_bounds__(256 * V2_GROUPS, 1) void fbank_logmel_kernel(const 
     __syncthreads();
   }
 #else
-  fbank2_pass<4, 0>(p, xs, base, stage, lane, wid, mel);
-  fbank2_pass<3, 4>(p, xs, base, stage, lane, wid, mel);
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mel[t][r] = 0.f;
+  fbank2_pass<4, 0, 0, false>(p, xs, base, stage, lane, wid, mel);
+  fbank2_pass<3, 4, 1, false>(p, xs, base, stage, lane, wid, mel);
   __syncthreads();                                    // every wave is done with its sample image
 
   // mel tile rows -> LDS [frame][mel] for the log / max / coalesced-store passes below
@@ -450,8 +476,8 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
   std::vector<_Float16> b16(V2_BASIS_BYTES / 2);
   {
     size_t o = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-      const int q0 = pass == 0 ? 0 : 4, nt = pass == 0 ? 4 : 3;
+    for (int pass = 0; pass < V2_NPASS; ++pass) {
+      const int q0 = fb_q0(pass), nt = fb_nt(pass);
       for (int st = 0; st < V2_KSTEPS; ++st)
         for (int qi = 0; qi < nt; ++qi)
           for (int kind = 0; kind < 4; ++kind)
