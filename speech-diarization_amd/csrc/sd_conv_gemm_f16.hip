@@ -572,7 +572,7 @@ __device__ __forceinline__ void sd_direct_epilogue(const sd_conv_args& p, ACC (&
 // (The N x N cosine affinity had a SYM form of this kernel in round 3: upper-triangle tiles + an LDS-transposed mirror; superseded by
 // sd_affinity.hip, whose 128 x 128 tiles leave two workgroups on a CU: 3.2 -> 2.3 ms for 50 k x 50 k.)
 template <typename TO, bool DIRECT, bool SPLIT = false>
-__global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec, const int total_tiles) {
+__global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec) {
   constexpr int TBK = 64;
   constexpr int TROW = 128;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -589,21 +589,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
   const int wm = wid >> 2, wn = wid & 3;
 
   const int n_tiles = (p.cout + TBN - 1) / TBN;
-  // XCD blockIdx % 8 owns a contiguous eighth of the tiles.  One tile per workgroup (gridDim = tiles), or — SD_T256_PERSIST builds —
-  // 32 resident workgroups per XCD that walk their XCD's tiles with stride 32 (no dispatch turnover between tiles)
-  int wg_first, wg_end, wg_step;
+  int wg;
   {
-    const int nwg = total_tiles, b = blockIdx.x;
+    const int nwg = gridDim.x, b = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    wg_first = first + (b >> 3);
-    if ((int)gridDim.x == total_tiles) { wg_end = wg_first + 1; wg_step = 1; }
-    else { wg_end = first + q + (xcd < r ? 1 : 0); wg_step = (int)gridDim.x >> 3; }
-  }
-  for (int wg = wg_first; wg < wg_end; wg += wg_step) {
-  if (wg != wg_first) {                                   // the ring is reused: every wave must have read its last fragments
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   const int tile_n = wg % n_tiles;
   const int tile_m = wg / n_tiles;
@@ -818,9 +808,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
       __syncthreads();
     }
 }
-#ifndef SD_STAMP
-  }   // tile loop
-#else
+#ifdef SD_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
   if (tid == 0 && blockIdx.x < 8192) {     // [prologue, K loop, epilogue incl. store drain, total] cycles, total in 100 MHz ticks
@@ -830,7 +818,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
     sd_stamp_buf[blockIdx.x * 8 + 3] = t_exit - t_entry;
     sd_stamp_buf[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime() - r_entry;
   }
-  }   // tile loop (stamp builds time one tile per workgroup)
 #endif
 }
 
@@ -1056,11 +1043,7 @@ int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
   {
     // work = the algorithmic (f32-equivalent) flops: a split row carries cin / 2 values
     SdProfScope prof(SD_PROF_CONV_WIDE, stream, (SPLIT ? 1.0 : 2.0) * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
-    long grid = tiles_m * tiles_n;
-#ifdef SD_T256_PERSIST           // A/B build: 32 persistent workgroups per XCD
-    if (grid > 256) grid = 256;
-#endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), R3_LDS_BYTES, stream, *a, vec, (int)(tiles_m * tiles_n));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), R3_LDS_BYTES, stream, *a, vec);
   }
   SD_CHECK_LAUNCH("conv_gemm_f16_t256_kernel");
   return SD_OK;
