@@ -129,6 +129,27 @@ __device__ __forceinline__ void af_step(f32x4 (&acc)[4][4], const char* a, const
     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 }
 
+// the same K step on EXACT f32 operands (v_mfma_f32_16x16x4_f32, the accumulator layout of the f16 form): a stage row is 32 f32 values in
+// the same 128 bytes, a lane reads four consecutive k (one ds_read_b128) at chunk fq (+ 4 for the second half) and feeds element r to
+// MFMA r, which therefore sums k in {4 fq + r} over the four lane groups; both operands use the same permutation
+__device__ __forceinline__ void af_step_f32(f32x4 (&acc)[4][4], const char* a, const char* b, int so_hi, int so_lo) {
+#pragma unroll
+  for (int c2 = 0; c2 < 2; ++c2) {
+    const int so = c2 ? so_lo : so_hi;
+    f32x4 av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(a + i * 16 * AF_ROW + so);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(b + j * 16 * AF_ROW + so);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][r], bv[j][r], acc[i][j], 0, 0, 0);
+  }
+}
+
 // acc[i][j][r] = K[rbase + 16 i + 4 fq + r][cbase + 16 j + fr] / alpha.  Off the diagonal both copies of the block leave as 4 rows x 256
 // contiguous bytes per wave instruction (diagnostic builds with the same bytes as 16 x 64 / 8 x 128 / 4 x 256 / 2 x 512 bytes per
 // instruction: 3.27 / 2.57 / 2.24 / 2.28 ms for the 50 k matrix), shuffled in registers:
@@ -202,9 +223,12 @@ __device__ __forceinline__ void af_epilogue(const f32x4 (&acc)[4][4], bool diag,
   }
 }
 
-__global__ __launch_bounds__(256, 2) void affinity_sym_split16_kernel(const _Float16* __restrict__ xs, const int ldx, const int N,
-                                                                     const int groups, float* __restrict__ out, const long ldo,
-                                                                     const float alpha, const int nt, const int nsup) {
+// EXACT = false: rows of SD_DT_SPLIT16 halves, three f16 products per value pair.  EXACT = true: rows of f32 values (zero padded to whole
+// groups of 32), exact f32 MFMA.  Either way a row of one group is 128 bytes and `ldx` is the row stride in BYTES.
+template <bool EXACT>
+__global__ __launch_bounds__(256, 2) void affinity_sym_kernel(const char* __restrict__ xs, const long ldx, const int N,
+                                                              const int groups, float* __restrict__ out, const long ldo,
+                                                              const float alpha, const int nt, const int nsup) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef SD_STAMP
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), r_entry = __builtin_amdgcn_s_memrealtime();
@@ -227,9 +251,9 @@ __global__ __launch_bounds__(256, 2) void affinity_sym_split16_kernel(const _Flo
   // staging role: thread (r0 = tid / 8, ps = tid % 8) fills physical slot ps of rows r0 + 32 i (i < 4) of both operands; the slot holds
   // logical 16-byte chunk ps ^ ((row >> 1) & 7), and (row >> 1) & 7 does not depend on i
   const int r0 = tid >> 3;
-  const int ls8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;
-  const _Float16* pa[4];
-  const _Float16* pb[4];
+  const int ls8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 16;     // bytes
+  const char* pa[4];
+  const char* pb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #ifdef SD_DIAG_SAME_PANELS       // timing-only diagnostic build: every tile loads rows 0 .. 255 (all L2 hits)
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void affinity_sym_split16_kernel(const _Flo
 #endif
     m = m < N ? m : N - 1;
     n = n < N ? n : N - 1;
-    pa[i] = xs + (size_t)m * ldx + ls8;
+    pa[i] = xs + (size_t)m * ldx + ls8;                   // (ldx, ls8 in bytes)
     pb[i] = xs + (size_t)n * ldx + ls8;
   }
   char* const dst = smem + (wid * 8) * AF_ROW;
@@ -253,12 +277,12 @@ __global__ __launch_bounds__(256, 2) void affinity_sym_split16_kernel(const _Flo
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       AF_GLDS16(pa[i], base + i * 32 * AF_ROW);
-      pa[i] += 64;
+      pa[i] += AF_ROW;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       AF_GLDS16(pb[i], base + AF_OPER + i * 32 * AF_ROW);
-      pb[i] += 64;
+      pb[i] += AF_ROW;
     }
   };
 
@@ -283,7 +307,8 @@ __global__ __launch_bounds__(256, 2) void affinity_sym_split16_kernel(const _Flo
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                        // step kt has landed; every wave is done with the stage of step kt - 1
     if (kt + 1 < groups) issue((kt + 1) & 1);
-    af_step(acc, a_base + (kt & 1) * AF_STAGE, b_base + (kt & 1) * AF_STAGE, so_hi, so_lo);
+    if constexpr (EXACT) af_step_f32(acc, a_base + (kt & 1) * AF_STAGE, b_base + (kt & 1) * AF_STAGE, so_hi, so_lo);
+    else af_step(acc, a_base + (kt & 1) * AF_STAGE, b_base + (kt & 1) * AF_STAGE, so_hi, so_lo);
   }
 #ifdef SD_STAMP
   const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
@@ -316,18 +341,31 @@ extern "C" int sd_debug_read_affinity_stamps(unsigned long long* out, int n) {
 }
 #endif
 
+namespace {
+template <bool EXACT>
+int launch_affinity(const void* xs, long ldx_bytes, int N, int groups, float* out, long ldo, float alpha, sd_stream_t stream, const char* who) {
+  if (N % 4 != 0 || ldo % 4 != 0 || !sd_aligned16(out) || !sd_aligned16(xs) || ldx_bytes % 16 != 0 || ldx_bytes < (long)AF_ROW * groups || groups <= 0)
+    return sd_set_error(SD_ERR_ARG, "%s: N=%d ldo=%ld row bytes=%ld groups=%d", who, N, ldo, ldx_bytes, groups);
+  const int nt = (N + AF_T - 1) / AF_T;
+  const int nsup = (nt + AF_SUP - 1) / AF_SUP;
+  const long nwg = (long)nsup * (nsup + 1) / 2 * (AF_SUP * AF_SUP);
+  if (nwg >= (1L << 31)) return sd_set_error(SD_ERR_ARG, "%s: N=%d needs %ld workgroups", who, N, nwg);
+  auto kern = affinity_sym_kernel<EXACT>;
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), AF_LDS));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), AF_LDS, static_cast<hipStream_t>(stream),
+                     static_cast<const char*>(xs), ldx_bytes, N, groups, out, ldo, alpha, nt, nsup);
+  SD_CHECK_LAUNCH(EXACT ? "affinity_sym_kernel<exact f32>" : "affinity_sym_kernel<split16x3>");
+  return SD_OK;
+}
+}  // namespace
+
 // xs: SD_DT_SPLIT16 [N][ldx halfs] (ldx = 2 x padded D, groups = padded D / 32), both operands; out f32 [N][ldo], N % 4 == 0,
 // ldo % 4 == 0, out 16-byte aligned; every entry = alpha x (row i . row j)
 int sd_affinity_sym_split16(const void* xs, int ldx, int N, int groups, float* out, long ldo, float alpha, sd_stream_t stream) {
-  if (N % 4 != 0 || ldo % 4 != 0 || !sd_aligned16(out) || ldx < 64 * groups || groups <= 0)
-    return sd_set_error(SD_ERR_ARG, "sd_affinity_sym_split16: N=%d ldo=%ld ldx=%d groups=%d", N, ldo, ldx, groups);
-  const int nt = (N + AF_T - 1) / AF_T;
-  const int nsup = (nt + AF_SUP - 1) / AF_SUP;
-  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(affinity_sym_split16_kernel), AF_LDS));
-  const long nwg = (long)nsup * (nsup + 1) / 2 * (AF_SUP * AF_SUP);
-  if (nwg >= (1L << 31)) return sd_set_error(SD_ERR_ARG, "sd_affinity_sym_split16: N=%d needs %ld workgroups", N, nwg);
-  hipLaunchKernelGGL(affinity_sym_split16_kernel, dim3((unsigned)nwg), dim3(256), AF_LDS, static_cast<hipStream_t>(stream),
-                     static_cast<const _Float16*>(xs), ldx, N, groups, out, ldo, alpha, nt, nsup);
-  SD_CHECK_LAUNCH("affinity_sym_split16_kernel");
-  return SD_OK;
+  return launch_affinity<false>(xs, 2L * ldx, N, groups, out, ldo, alpha, stream, "sd_affinity_sym_split16");
+}
+
+// xn: f32 [N][ldx floats], columns past D zero up to groups x 32; exact f32 products, K[i][j] and K[j][i] the same bits
+int sd_affinity_sym_f32(const float* xn, int ldx, int N, int groups, float* out, long ldo, sd_stream_t stream) {
+  return launch_affinity<true>(xn, 4L * ldx, N, groups, out, ldo, 1.0f, stream, "sd_affinity_sym_f32");
 }

@@ -156,6 +156,9 @@ extern "C" int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row
   // the whole matrix: tiles on and above the diagonal, each stored as is and transposed (half the MFMA work;
   // K[i][j] and K[j][i] are then the same bits).  SD_AFFINITY_SYM=0 (diagnostic) computes every tile.
   static const bool sym = [] { const char* e = sd_experiment_env("SD_AFFINITY_SYM"); return !e || atoi(e) != 0; }();
+  static const bool own = [] { const char* e = sd_experiment_env("SD_AFFINITY_CONV"); return !(e && atoi(e) != 0); }();   // SD_AFFINITY_CONV=1: round 2's conv-kernel form
+  if (sym && own && row_lo == 0 && row_hi == N && N % 4 == 0 && ldo % 4 == 0 && sd_aligned16(out))
+    return sd_affinity_sym_f32(xn, Dp, N, Dp / 32, out, ldo, stream);       // sd_affinity.hip: 16x16x4 f32 MFMA, two workgroups per CU, 256-byte stores
   if (sym && row_lo == 0 && row_hi == N) return sd_conv1d_cl_f32_symmetric(&a, stream);
   return sd_conv1d_cl_f32(&a, stream);
 }

@@ -212,16 +212,19 @@ def test_cosine_affinity_split16_triangle_and_mirror(dev, n, pad):
         assert (blk - k[lo:hi]).abs().max() < 1e-6
 
 
-@pytest.mark.parametrize("n,pad", [(1500, 0), (2500, 0), (3000, 4), (3001, 0), (3001, 3), (4100, 0), (8200, 0)])
+@pytest.mark.parametrize("n,pad", [(4, 0), (132, 4), (1500, 0), (2500, 0), (3000, 4), (3001, 0), (3001, 3), (3002, 2), (4100, 0), (8200, 0)])
 def test_cosine_affinity_triangle_and_mirror(dev, n, pad):
-    """The full matrix is computed on and above the diagonal (bands of 8 tile rows) and mirrored: every element must be
-    there, K must be exactly symmetric, and carry the bits the row-block entry point (which computes every tile) produces.  Sizes: 12 / 20 / 24 / 33 / 65 tiles per side (partial last bands), rows that are not a
-    multiple of 4 (scalar tails), a padded row stride (16-byte stores stay aligned)."""
+    """The full matrix is computed on and above the diagonal and mirrored: every element must be there and K must be exactly
+    symmetric.  N % 4 == 0 with aligned rows: `sd_affinity.hip`'s exact-f32 form (16x16x4 MFMA, 128 x 128 tiles in 8 x 8 super-tiles,
+    both copies of a tile from the same accumulators) -- within 1e-6 of the row-block entry point, which sums in another order.
+    Otherwise the conv kernel's triangle (bands of 8 tile rows, scalar tails) -- the row-block entry point's bits.  Sizes: 12 .. 65
+    tiles per side (partial last bands / super-tiles), a padded row stride (16-byte stores stay aligned)."""
     from sklearn.metrics.pairwise import cosine_similarity
     from speech_diarization_amd import ops
     rng = np.random.default_rng(n)
     x = rng.standard_normal((n, 192)).astype(np.float32) * rng.uniform(0.1, 10.0, size=(n, 1)).astype(np.float32)
-    x[11] = 0.0
+    if n > 11:
+        x[11] = 0.0
     xd = torch.from_numpy(x).to(dev)
     buf = torch.full((n, n + pad), float("nan"), device=dev)
     k = ops.cosine_affinity(xd, out=buf[:, :n])
@@ -229,14 +232,20 @@ def test_cosine_affinity_triangle_and_mirror(dev, n, pad):
     if pad:
         assert torch.isnan(buf[:, n:]).all()          # nothing written past a row
     assert torch.equal(k, k.T)
-    assert torch.equal(ops.cosine_affinity(xd, rows=(0, n - 1)), k[: n - 1])      # same kernel, every tile computed
+    every = ops.cosine_affinity(xd, rows=(0, n - 1))                               # every tile computed by the conv kernel
+    if n % 4 == 0 and pad % 4 == 0:
+        assert (every - k[: n - 1]).abs().max() < 1e-6
+    else:
+        assert torch.equal(every, k[: n - 1])                                      # the same kernel
     for lo, hi in ((0, 130), (n // 2 - 64, n // 2 + 200), (n - 131, n)):          # (few tiles: the split-K kernel sums in another order)
+        lo, hi = max(lo, 0), min(hi, n)
         blk = ops.cosine_affinity(xd, rows=(lo, hi))
         assert (blk - k[lo:hi]).abs().max() < 1e-6
-    if n <= 3001:
+    if n <= 3002:
         ref = cosine_similarity(x.astype(np.float64))
         assert np.abs(k.cpu().numpy() - ref).max() < 2e-6
-    assert torch.all(k[11] == 0) and torch.all(k[:, 11] == 0)
+    if n > 11:
+        assert torch.all(k[11] == 0) and torch.all(k[:, 11] == 0)
 
 
 def test_cosine_affinity_identity_and_empty(dev):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (a --variant built with -DSD_STAMP): per-workgroup cycles of the split16x3 affinity's 128 x 128 tiles
-(affinity_sym_split16_kernel, sd_affinity.hip): prologue / K loop / store issue / store drain, and the in-kernel clock.
+(affinity_sym_kernel, sd_affinity.hip): prologue / K loop / store issue / store drain, and the in-kernel clock.
 
     python speech-diarization_amd/build_native.py --variant stamp "-DSD_STAMP"
     SD_EXPERIMENT=1 SD_HIP_LIB=speech-diarization_amd/variants/libsd_hip_stamp.so python tools/stamp_affinity.py [N]
