@@ -1,3 +1,6 @@
+// N x N cosine affinity, upper triangle + mirror, in two arithmetic forms of one kernel: exact f32 (rows of f32 values,
+// v_mfma_f32_16x16x4_f32) and split16x3 (SD_DT_SPLIT16 rows, three v_mfma_f32_16x16x32_f16 products per value pair: f32-level accuracy
+// at the f16 rate).  The notes below were written for the split form:
 // N x N cosine affinity from SD_DT_SPLIT16 rows: the write-bound form of SURVEY 8(d)'s affinity row
 // (4 N^2 bytes out, 3 x 2 N^2 D f16 flops on the upper triangle only) [REF anti_stick_diarize.py:176-177, diar_diag.py:215-219].
 //

@@ -122,8 +122,9 @@ extern "C" size_t sd_cosine_workspace_bytes(int N, int D) {
 // sklearn.metrics.pairwise.cosine_similarity(X): K = normalize(X) @ normalize(X).T with
 // zero-norm rows left as zeros, dtype preserved [REF anti_stick_diarize.py:177]
 // [REF diar_diag.py:215,219,278,355].  Rows are normalised once into the workspace
-// (zero padded to a multiple of 32 columns) and the product runs on the f32 matrix
-// cores through the same implicit-GEMM operator as the pointwise convs.
+// (zero padded to a multiple of 32 columns); the whole matrix runs on sd_affinity.hip's
+// triangle + mirror kernel (exact f32 MFMA), a row block (multi-GPU) or an unaligned output
+// through the same implicit-GEMM operator as the pointwise convs.
 extern "C" int sd_cosine_affinity_f32(const float* x, int N, int D, float* out, int ldo,
                                       void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
   return sd_cosine_affinity_rows_f32(x, N, D, 0, N, out, ldo, ws_dev, ws_bytes, stream);
