@@ -364,7 +364,7 @@ def main():
         a_flops = 384.0 * a_rows * n_total
         if affinity_ms > 0:
             out["roofline_affinity"] = {
-                "kernel": "l2norm_rows_kernel + conv_gemm_f32_kernel (x == w: upper triangle + mirror when the block is the full matrix)",
+                "kernel": "l2norm_rows_kernel + affinity_sym_kernel<exact f32> (sd_affinity.hip: upper triangle + mirror) when the block is the full matrix, conv_gemm_f32_kernel for a row block (N > 1 ranks)",
                 "rows": a_rows, "cols": n_total, "avg_call_ms": affinity_ms, "share_of_step_time": affinity_ms * 1e-3 * args.steps / dt,
                 "bytes": {"bound": "hbm", "achieved": a_bytes / (affinity_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": a_bytes / (affinity_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": a_bytes},
