@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split16_n128_kernel(const sd
     }
   }
   __syncthreads();
-  sd_store_tile<TO, BM, BN, 256>(p, Cs, LDC, m0, n0, tid, vec);
+  sd_store_tile<TO, BM, BN, 256, 2, 3, true>(p, Cs, LDC, m0, n0, tid, vec);      // (the only kernel that may write y as SD_DT_SPLIT16)
 }
 
 #ifdef SD_STAMP
@@ -1207,7 +1207,7 @@ extern "C" int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int
 
 // x plain f32 (split while staging): the 128x128 kernel
 static int conv1d_cl_split16_narrow(const sd_conv_args* a, hipStream_t stream) {
-  SD_CHECK_ARG(a->w_dtype == SD_DT_SPLIT16 && a->y_dtype == SD_DT_F32, "sd_conv1d_cl_split16: w must be SD_DT_SPLIT16, y f32");
+  SD_CHECK_ARG(a->w_dtype == SD_DT_SPLIT16 && (a->y_dtype == SD_DT_F32 || a->y_dtype == SD_DT_SPLIT16), "sd_conv1d_cl_split16: w must be SD_DT_SPLIT16, y f32 or SD_DT_SPLIT16");
   SD_CHECK_ARG(a->M > 0 && a->T > 0 && a->M % a->T == 0, "sd_conv1d_cl_split16: M=%d must be a positive multiple of T=%d", a->M, a->T);
   SD_CHECK_ARG(a->cin > 0 && a->cin % 4 == 0 && a->cin_pad >= a->cin && a->cin_pad % 32 == 0, "sd_conv1d_cl_split16: cin=%d (a multiple of 4) cin_pad=%d (of 32)", a->cin, a->cin_pad);
   SD_CHECK_ARG(a->cout > 0 && a->taps >= 1 && (a->taps & 1) && a->dil >= 1 && (a->taps / 2) * a->dil < a->T, "sd_conv1d_cl_split16: cout=%d taps=%d dil=%d T=%d", a->cout, a->taps, a->dil, a->T);
@@ -1229,6 +1229,9 @@ static int conv1d_cl_split16_narrow(const sd_conv_args* a, hipStream_t stream) {
     vec = vec && a->tee_lo % 8 == 0 && a->tee_hi % 8 == 0 && a->ldt % 8 == 0 && sd_aligned16(a->tee);
     if (a->tee_add) vec = vec && a->ld_ta % 8 == 0 && a->ta_col0 % 8 == 0 && sd_aligned16(a->tee_add);
   }
+  if (a->y_dtype == SD_DT_SPLIT16)      // y written as split halves by the shared epilogue's vector path (ldo in VALUE columns)
+    SD_CHECK_ARG(vec && a->ldo % 32 == 0, "sd_conv1d_cl_split16: an SD_DT_SPLIT16 output needs ldo %% 32 == 0 and the aligned (vector) epilogue (ldo=%d o_col0=%d cout=%d)",
+                 a->ldo, a->o_col0, a->cout);
   auto kern = conv_gemm_split16_n128_kernel<float>;
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), STAGE_BYTES));
   {

@@ -35,6 +35,7 @@ struct Buffers {
   void *x0, *r, *t2, *xcat, *h, *s0, *s1, *a1, *e;   // activation dtype (e = attention logits)
   void* xs;                                            // split16 mode: the SD_DT_SPLIT16 copy of a wide conv's input (pack scratch)
   void* xcs;                                           // split16 mode: SD_DT_SPLIT16 twin of xcat, written by the SE scale + residual kernel
+  void* rs;                                            // split16 mode: the Res2Net output r as SD_DT_SPLIT16 (tdnn2's input), written by the narrow convs
   void* wpk; size_t wpk_bytes;                        // Res2Net chain weights in fragment order (f16 path)
   float *semean, *seh, *gate, *stats, *gbias, *pooled;
   size_t bytes;
@@ -68,6 +69,7 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.wpk = c.take(b.wpk_bytes, 1);
   b.xs = (w->split16 == 1 && act_dtype == SD_DT_F32) ? c.take(M * (size_t)((Cm + 31) / 32 * 32), 4) : nullptr;
   b.xcs = (w->split16 == 1 && act_dtype == SD_DT_F32 && Cm % 32 == 0 && C % 32 == 0) ? c.take(M * (size_t)Cm, 4) : nullptr;
+  b.rs = (w->split16 == 1 && act_dtype == SD_DT_F32 && C % 32 == 0 && (C / w->res2_scale) % 32 == 0) ? c.take(M * (size_t)C, 4) : nullptr;
   b.a1 = b.x0;    // block-0 output is dead once block 1 has consumed it
   b.e = b.xcat;
   b.bytes = c.off;
@@ -136,8 +138,10 @@ int run_conv(const sd_conv_args& a, sd_stream_t stream) {
 // A narrow layer of the f32 schedule (Res2Net convs, attention TDNN): in split16 mode, when it carries the second packing, the
 // 128x128 split kernel (f32 activations split while staged; tee / tee_add / per-segment bias as in the exact kernel).
 int run_narrow(const sd_layer& l, sd_conv_args a, bool split, sd_stream_t stream) {
-  if (!(split && l.w_split && !l.bias_split && a.x_dtype == SD_DT_F32 && a.y_dtype == SD_DT_F32 && !a.colstat))
+  if (!(split && l.w_split && !l.bias_split && a.x_dtype == SD_DT_F32 && !a.colstat)) {
+    if (a.y_dtype == SD_DT_SPLIT16) return sd_set_error(SD_ERR_UNSUPPORTED, "sd_ecapa_forward: a split output needs the split narrow kernel");
     return run_conv(a, stream);
+  }
   a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = (l.cin + 31) / 32 * 32;
   a.w_scale_inv = l.split_scale_inv;
   return sd_conv1d_cl_split16(&a, stream);
@@ -229,6 +233,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       return !(e && e[0] == '0');
     }();
     const sd_layer& r2 = blk.res2[0];
+    bool r_split = false;                                // this block's Res2Net output exists as SD_DT_SPLIT16 (b.rs) instead of f32 chunks in b.r
     const bool chain = chain_ok && dt == SD_DT_F16 && w->res2_scale >= 2 &&
                        sd_res2net_chain_supported(T, chunk, w->res2_scale - 1, r2.taps, r2.dil);
     {
@@ -240,10 +245,17 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     if (chain) {
       SD_TRY(sd_res2net_chain_f16(b.r, C, B, T, blk.res2, w->res2_scale - 1, b.wpk, b.wpk_bytes, stream));
     } else {
+      // f32-split16x3 with the wide layers split too: tdnn2 reads r as SD_DT_SPLIT16, so the narrow convs write their chunk in that
+      // form directly (same bytes as the f32 chunk, no pack pass: 8 of the pass's 8 bytes per value go) and only chunk 0, which
+      // tdnn1's output passes through unchanged, is packed; r itself keeps tdnn1's output (the tee_add source of every conv)
+      r_split = wsplit && b.rs && blk.tdnn2.w_split && !wide_goes_narrow(blk.tdnn2, M);
+      for (int j = 1; j < w->res2_scale && r_split; ++j) r_split = blk.res2[j - 1].w_split != nullptr;
+      if (r_split) SD_TRY(sd_split16_pack_f32(static_cast<const float*>(b.r), C, 0, M, chunk, 1.f, b.rs, C, stream));
       for (int j = 1; j < w->res2_scale; ++j) {
         void* src = (j & 1) ? b.s0 : b.s1;
         void* dst = (j & 1) ? b.s1 : b.s0;
         sd_conv_args a = conv_of(blk.res2[j - 1], src, dt, chunk, 0, b.r, dt, C, j * chunk, M, T, SD_ACT_RELU);
+        if (r_split) { a.y = b.rs; a.y_dtype = SD_DT_SPLIT16; }
         if (j + 1 < w->res2_scale) {
           a.tee = dst; a.ldt = chunk; a.tee_lo = 0; a.tee_hi = chunk;
           a.tee_add = b.r; a.ld_ta = C; a.ta_col0 = (j + 1) * chunk;
@@ -258,7 +270,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && C % 256 == 0 && !(wsplit && blk.tdnn2.w_split && wide_goes_narrow(blk.tdnn2, M)) &&
                         sd_colstat_floats(M, C) * sizeof(float) <= (size_t)M * chunk * es;
       if (stat) a.colstat = static_cast<float*>(b.s0);
-      SD_TRY(run_wide(blk.tdnn2, a, wsplit, b.xs, stream));
+      SD_TRY(run_wide(blk.tdnn2, a, wsplit, b.xs, stream, r_split ? b.rs : nullptr, C));
       if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
       else SD_TRY(sd_seg_mean_std_dt(b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
     }

@@ -108,7 +108,7 @@ __device__ __forceinline__ void sd_store_tile_scalar(const sd_conv_args& p, cons
 // are all fetched before the first store (so the rows cannot go out in small chunks).
 // FULL: every row of the tile exists (straight-line code); otherwise the thread's first `np` passes
 // do (the tile hangs over row M) and the rest are predicated off.
-template <typename TO, int PASSES, int RPP, bool TEE, bool TADD, bool STAT, bool FULL, int PARTS = 3>
+template <typename TO, int PASSES, int RPP, bool TEE, bool TADD, bool STAT, bool FULL, int PARTS = 3, bool YSPLIT = false>
 __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float* c, int ldc, size_t row0, int n8,
                                               const float* b8, const float* s8, const float* h8, float lo,
                                               int rr0, int rb, float (*st)[8], int np) {
@@ -138,7 +138,26 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[i][e] = fmaxf(v[i][e] + b8[e], lo) * s8[e] + h8[e];
       const bool live = FULL || c0 + i < np;
-      if (live) SdOut<TO>::store8(y + (size_t)(c0 + i) * RPP * p.ldo, v[i]);
+      if (YSPLIT && sizeof(TO) == 4 && p.y_dtype == SD_DT_SPLIT16) {      // (YSPLIT: only the kernels whose host entry accepts such a y)
+        // y as SD_DT_SPLIT16 rows of p.ldo VALUE columns (what sd_split16_pack_f32 would make of the f32 result, bit for bit:
+        // hi = f16(v), lo = f16(v - hi), [hi x 32 | lo x 32] per 32 columns); the host guarantees ldo % 32 == 0, (o_col0 + n8) % 8 == 0
+        if (live) {
+          typedef _Float16 h8s __attribute__((ext_vector_type(8)));
+          const int col = p.o_col0 + n8;
+          _Float16* ys = static_cast<_Float16*>(p.y) + (row0 + (size_t)(c0 + i) * RPP) * 2 * p.ldo + (col >> 5) * 64 + (col & 31);
+          h8s hi, lo;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float w = __builtin_amdgcn_fmed3f(v[i][e], -65504.f, 65504.f);
+            hi[e] = (_Float16)w;
+            lo[e] = (_Float16)(w - (float)hi[e]);
+          }
+          *reinterpret_cast<h8s*>(ys) = hi;
+          *reinterpret_cast<h8s*>(ys + 32) = lo;
+        }
+      } else if (live) {
+        SdOut<TO>::store8(y + (size_t)(c0 + i) * RPP * p.ldo, v[i]);
+      }
       if (STAT) {
         // column statistics of this thread's rows, split at the segment boundaries rb, rb + T (tile-relative);
         // taken about the pivot h8 (the BatchNorm shift) so that sum((x - pivot)^2) does not cancel
@@ -172,7 +191,7 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
 // selects such a kernel for a tee_add layer; saves the registers of the prefetched rows).
 // STAT_PARTS: segments a tile may span for the column statistics: 3 (T >= ROWS / 2) or 2 (T >= ROWS: the
 // 256x256 kernel, which has no registers for the third set of accumulators).
-template <typename TO, int ROWS, int COLS, int NT, int TEE_MODE = 2, int STAT_PARTS = 3>
+template <typename TO, int ROWS, int COLS, int NT, int TEE_MODE = 2, int STAT_PARTS = 3, bool YSPLIT = false>
 __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, int ldc, int m0, int n0, int tid, int vec) {
   constexpr int TPR = COLS / 8;     // threads per tile row
   constexpr int RPP = NT / TPR;     // rows per pass
@@ -234,8 +253,8 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
   const size_t row0 = (size_t)(m0 + (rr0 < nrows ? rr0 : 0));
 #define SD_ROWS(TEE_, TADD_, STAT_, ST_, RB_)                                                                            \
   do {                                                                                                                   \
-    if (full) sd_store_rows<TO, PASSES, RPP, TEE_, TADD_, STAT_, true>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, RB_, ST_, PASSES); \
-    else sd_store_rows<TO, PASSES, RPP, TEE_, TADD_, STAT_, false>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, RB_, ST_, np);        \
+    if (full) sd_store_rows<TO, PASSES, RPP, TEE_, TADD_, STAT_, true, 3, YSPLIT>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, RB_, ST_, PASSES); \
+    else sd_store_rows<TO, PASSES, RPP, TEE_, TADD_, STAT_, false, 3, YSPLIT>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, RB_, ST_, np);        \
   } while (0)
   if (p.colstat) {
     // (host: only with relu / identity, a per-channel bias, cout % COLS == 0, no tee and T >= ROWS / 2, so

@@ -117,12 +117,12 @@ def pack_weight_split16(w: torch.Tensor | np.ndarray, device):
 def conv1d_cl_split16(x: torch.Tensor, w_split: torch.Tensor, w_shift: int, T: int, *, cin: int, dil: int = 1, bias=None, bias_per_seg=False,
                       act=None, scale=None, shift=None, act2=None, a_col0: int = 0, out: torch.Tensor | None = None, o_col0: int = 0,
                       tee: torch.Tensor | None = None, tee_lo: int = 0, tee_hi: int = 0, tee_add: torch.Tensor | None = None, ta_col0: int = 0,
-                      colstat: torch.Tensor | None = None, narrow: bool = False) -> torch.Tensor:
+                      colstat: torch.Tensor | None = None, narrow: bool = False, out_split: torch.Tensor | None = None) -> torch.Tensor:
     """The "f32-split16x3" conv: f32 x [M, lda] -> f32 y [M, ldo] at f32-level accuracy on the f16 matrix cores.
     `w_split`, `w_shift` from `pack_weight_split16`; bias / scale / shift are the layer's ordinary f32 vectors.
     Default (wide outputs): `sd_split16_pack_f32` + the 256x256 kernel, the 2^s of the weight scaling folded into bias and scale here.
     `narrow=True`: the 128x128 kernel that splits the f32 activations while staging them (no pack pass; tee_add, per-segment bias and
-    act2 allowed, no colstat), the 2^-s passed as `w_scale_inv`."""
+    act2 allowed, no colstat), the 2^-s passed as `w_scale_inv`; `out_split`: its y as SD_DT_SPLIT16 rows instead of f32."""
     _need_cuda(x, w_split, bias, scale, shift, out, tee, tee_add, colstat)
     lib = N.load()
     cout, taps, chunks, _ = w_split.shape
@@ -151,6 +151,14 @@ def conv1d_cl_split16(x: torch.Tensor, w_split: torch.Tensor, w_shift: int, T: i
     a.w, a.w_dtype = w_split.data_ptr(), N.SD_DT_SPLIT16
     a.y_dtype = N.SD_DT_F32
     a.y, a.ldo, a.o_col0 = out.data_ptr(), out.stride(0), o_col0
+    if out_split is not None:
+        # narrow kernel only: y leaves as SD_DT_SPLIT16 rows (f16 [M, 2 * ld], ld VALUE columns, a multiple of 32) instead of f32 --
+        # bit for bit what split16_pack would make of the f32 result; `out` is then not written
+        if not narrow or out_split.dtype != torch.float16 or out_split.stride(1) != 1 or out_split.shape[1] % 64:
+            raise TypeError("out_split: f16 [M, 2 * ld] with ld % 32 == 0, narrow kernel only")
+        _need_cuda(out_split)
+        a.y_dtype = N.SD_DT_SPLIT16
+        a.y, a.ldo = out_split.data_ptr(), out_split.shape[1] // 2
     a.M, a.T = M, T
     a.cin, a.cin_pad, a.cout, a.taps, a.dil = cin, cp, cout, taps, dil
     a.bias_per_seg = int(bool(bias_per_seg))

@@ -176,6 +176,31 @@ def test_conv1d_cl_split16_narrow_epilogues(dev):
     assert (ys - y32).abs().max() < 2e-6
 
 
+def test_narrow_split16_conv_writes_split_output(dev):
+    """The narrow kernel with y as SD_DT_SPLIT16 rows (what tdnn2 of the f32-split16x3 schedule reads): bit for bit the pack of its f32
+    result, written into a channel slice of a wider row; the tee (+ tee_add) copy stays f32; rows past the slice untouched."""
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, hid, C = 3, 201, 128, 384
+    x = torch.randn(B * T, hid, generator=g).to(dev)
+    nxt = torch.randn(B * T, C, generator=g).to(dev)
+    w = torch.randn(hid, hid, 3, generator=g) / 14
+    bias, scale, shift = torch.randn(hid, generator=g).to(dev), (torch.rand(hid, generator=g) + 0.5).to(dev), torch.randn(hid, generator=g).to(dev)
+    ws, s = ops.pack_weight_split16(w, dev)
+    kw = dict(cin=hid, dil=3, bias=bias, act="relu", scale=scale, shift=shift, o_col0=128, tee_lo=0, tee_hi=hid, tee_add=nxt, ta_col0=256)
+    y32 = torch.zeros(B * T, C, device=dev)
+    tee32 = torch.zeros(B * T, hid, device=dev)
+    ops.conv1d_cl_split16(x, ws, s, T, narrow=True, out=y32, tee=tee32, **kw)
+    ysp = torch.full((B * T, 2 * C), 7.0, device=dev, dtype=torch.float16)
+    tee2 = torch.zeros(B * T, hid, device=dev)
+    dummy = torch.zeros(B * T, C, device=dev)
+    ops.conv1d_cl_split16(x, ws, s, T, narrow=True, out=dummy, out_split=ysp, tee=tee2, **kw)
+    want = ops.split16_pack(y32, 128, hid)                   # [M, 2 * 128]: the four groups of the slice
+    assert torch.equal(ysp[:, 256:512], want)
+    assert bool((ysp[:, :256] == 7.0).all()) and bool((ysp[:, 512:] == 7.0).all()) and bool((dummy == 0).all())
+    assert torch.equal(tee2, tee32)
+
+
 @pytest.mark.parametrize("B,n", [(4, 32000), (5, 16000), (2, 100000), (3, 9600)])
 def test_ecapa_split16_full_geometry_matches_oracle(dev, B, n):
     """The exact-f32 path's full-geometry test (tests/test_gpu_fbank_ecapa.py) with the SAME bars, on the split16x3 engine;
