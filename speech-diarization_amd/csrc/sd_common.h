@@ -19,7 +19,8 @@ int sd_affinity_sym_f32(const float* xn, int ldx, int N, int groups, float* out,
 int sd_affinity_sym_split16(const void* xs, int ldx, int N, int groups, float* out, long ldo, float alpha, sd_stream_t stream);   // sd_affinity.hip
 int sd_cast_f32_f16(const float* x, long n, void* y, sd_stream_t stream);           // sd_pool.hip
 int sd_se_scale_residual_split(const void* x, int ldx, const float* gate, const void* res, int ldr, int r_col0, void* y, int ldy, int y_col0,
-                               int B, int T, int C, int dtype, void* ys, int lds, int s_col0, sd_stream_t stream);   // sd_pool.hip
+                               int B, int T, int C, int dtype, void* ys, int lds, int s_col0, sd_stream_t stream,
+                               const void* res_split, int ld_rs, int rs_col0, int write_y);   // sd_pool.hip
 
 #define SD_CHECK_ARG(cond, ...)                            \
   do {                                                     \

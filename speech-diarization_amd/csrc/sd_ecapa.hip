@@ -223,6 +223,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     SD_TRY(run_wide(w->block0, a, wsplit, b.xs, stream));
   }
   const void* xin = b.x0; int ldin = C, colin = 0;
+  bool res_is_twin = false;                              // the current block input's f32 form was not written (read its SD_DT_SPLIT16 copy)
   for (int i = 0; i < w->n_blocks; ++i) {
     const sd_se_res2_block& blk = w->blocks[i];
     // Res2Net chain: y_j = TDNN_j(c_j + y_{j-1}), written over chunk j of r.  f16: one kernel per block keeps the
@@ -282,8 +283,20 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       SD_TRY(run_conv(a2, stream));
     }
     // gate * t2 + shortcut -> slice i of the MFA input
-    SD_TRY(sd_se_scale_residual_split(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, dt,
-                                      wsplit ? b.xcs : nullptr, Cm, i * C, stream));
+    {
+      // f32-split16x3 with the wide layers split: every reader of this slice of the MFA input takes its SD_DT_SPLIT16 copy (the next
+      // block's tdnn1, the MFA conv, and the next block's shortcut below), so the f32 slice is not written and the shortcut is read
+      // from the copy the previous block wrote -- unless a small launch routes the next tdnn1 to the narrow kernel, which stages f32
+      const bool twin = wsplit && b.xcs != nullptr;
+      const bool next_reads_f32 = i + 1 < w->n_blocks && wide_goes_narrow(w->blocks[i + 1].tdnn1, M);
+      const bool skip_f32 = twin && w->mfa.w_split && !wide_goes_narrow(w->mfa, M) && !next_reads_f32 &&
+                            (i + 1 >= w->n_blocks || w->blocks[i + 1].tdnn1.w_split);
+      const bool res_twin = twin && i > 0 && res_is_twin;
+      SD_TRY(sd_se_scale_residual_split(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, dt,
+                                        twin ? b.xcs : nullptr, Cm, i * C, stream,
+                                        res_twin ? b.xcs : nullptr, Cm, (i - 1) * C, skip_f32 ? 0 : 1));
+      res_is_twin = skip_f32;                            // the next block's shortcut exists only as the split copy
+    }
     xin = b.xcat; ldin = Cm; colin = i * C;
   }
   // multi-layer feature aggregation; the global mean / std of attentive pooling likewise from the

@@ -101,7 +101,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void se_scale_residual_kernel(const T* x, int ldx, const float* gate,
                                                                 const T* res, int ldr, int r_col0,
                                                                 T* y, int ldy, int y_col0,
-                                                                int M, int Tn, int C, _Float16* ys = nullptr, int lds = 0, int s_col0 = 0) {
+                                                                int M, int Tn, int C, _Float16* ys = nullptr, int lds = 0, int s_col0 = 0,
+                                                                const _Float16* rsp = nullptr, int ld_rsp = 0, int rsp_col0 = 0, int write_y = 1) {
   constexpr int VEC = 16 / sizeof(T);                 // 4 f32 or 8 f16 channels per lane
   typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
   const int groups = C / VEC;                          // channel groups per row
@@ -117,11 +118,25 @@ __global__ __launch_bounds__(256) void se_scale_residual_kernel(const T* x, int 
     for (int gq = tg; gq < groups; gq += gpr) {
       const int c = gq * VEC;
       const vec_t xv = *reinterpret_cast<const vec_t*>(xr + c);
-      const vec_t rv = *reinterpret_cast<const vec_t*>(rr + c);
+      vec_t rv;
+      if constexpr (sizeof(T) == 4) {
+        if (rsp) {      // the shortcut as the SD_DT_SPLIT16 copy a previous call wrote: hi + lo (the value the split convs see)
+          typedef _Float16 h4r __attribute__((ext_vector_type(4)));
+          const int rc = rsp_col0 + c;
+          const _Float16* d = rsp + (size_t)m * 2 * ld_rsp + 64 * (rc / 32) + (rc % 32);
+          const h4r hi = *reinterpret_cast<const h4r*>(d), lo = *reinterpret_cast<const h4r*>(d + 32);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rv[e] = (float)hi[e] + (float)lo[e];
+        } else {
+          rv = *reinterpret_cast<const vec_t*>(rr + c);
+        }
+      } else {
+        rv = *reinterpret_cast<const vec_t*>(rr + c);
+      }
       vec_t o;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o[e] = (T)((float)xv[e] * g[c + e] + (float)rv[e]);
-      *reinterpret_cast<vec_t*>(yr + c) = o;
+      if (write_y) *reinterpret_cast<vec_t*>(yr + c) = o;
       if constexpr (sizeof(T) == 4) {
         if (ys) {
           typedef _Float16 h4v __attribute__((ext_vector_type(4)));
@@ -412,13 +427,16 @@ extern "C" int sd_seg_mean_std_f32(const float* x, int ld, int col0, int B, int 
 
 extern "C" int sd_se_scale_residual_dt(const void* x, int ldx, const float* gate, const void* res, int ldr, int r_col0,
                                        void* y, int ldy, int y_col0, int B, int T, int C, int dtype, sd_stream_t stream) {
-  return sd_se_scale_residual_split(x, ldx, gate, res, ldr, r_col0, y, ldy, y_col0, B, T, C, dtype, nullptr, 0, 0, stream);
+  return sd_se_scale_residual_split(x, ldx, gate, res, ldr, r_col0, y, ldy, y_col0, B, T, C, dtype, nullptr, 0, 0, stream, nullptr, 0, 0, 1);
 }
 
 // library-internal: the same, plus (f32 only) an SD_DT_SPLIT16 copy of the result at value column s_col0 of ys [B*T][lds]
 int sd_se_scale_residual_split(const void* x, int ldx, const float* gate, const void* res, int ldr, int r_col0,
                                void* y, int ldy, int y_col0, int B, int T, int C, int dtype, void* ys, int lds, int s_col0,
-                               sd_stream_t stream) {
+                               sd_stream_t stream, const void* res_split, int ld_rs, int rs_col0, int write_y) {
+  if (res_split || !write_y)      // (f32-split16x3 schedule: the shortcut read from the split copy, the f32 result not written)
+    SD_CHECK_ARG(dtype == SD_DT_F32 && ys && (!res_split || (ld_rs % 32 == 0 && rs_col0 % 4 == 0 && rs_col0 + C <= ld_rs && sd_aligned16(res_split))),
+                 "sd_se_scale_residual: a split shortcut / no f32 result need f32 activations and the split copy of the result");
   if (ys) SD_CHECK_ARG(dtype == SD_DT_F32 && lds % 32 == 0 && s_col0 % 4 == 0 && s_col0 + C <= lds && sd_aligned16(ys),
                        "sd_se_scale_residual: the split copy needs f32 activations, lds %% 32 == 0, an aligned slice inside the row");
   if (int e = check_cl_dt("sd_se_scale_residual(x)", x, dtype, ldx, 0, C)) return e;
@@ -441,7 +459,7 @@ int sd_se_scale_residual_split(const void* x, int ldx, const float* gate, const 
   else
     hipLaunchKernelGGL(se_scale_residual_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(x), ldx, gate,
                        static_cast<const float*>(res), ldr, r_col0, static_cast<float*>(y), ldy, y_col0, M, T, C,
-                       static_cast<_Float16*>(ys), lds, s_col0);
+                       static_cast<_Float16*>(ys), lds, s_col0, static_cast<const _Float16*>(res_split), ld_rs, rs_col0, write_y);
   SD_CHECK_LAUNCH("se_scale_residual_kernel");
   return SD_OK;
 }
