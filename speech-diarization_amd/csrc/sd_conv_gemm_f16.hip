@@ -804,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
         }
       }
       __syncthreads();
-      sd_store_tile<TO, TBM / 2, TBN, 512, 1, 2>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);
+      sd_store_tile<TO, TBM / 2, TBN, 512, 1, 2, SPLIT>(p, Cs, TBN, m0 + hm * (TBM / 2), n0, tid, vec);      // (SPLIT: y may be SD_DT_SPLIT16)
       __syncthreads();
     }
 }
@@ -1247,8 +1247,8 @@ extern "C" int sd_conv1d_cl_split16(const sd_conv_args* a, sd_stream_t stream_) 
   SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_split16: null args");
   SD_CHECK_ARG(a->x && a->w && a->y, "sd_conv1d_cl_split16: null x/w/y");
   if (a->x_dtype == SD_DT_F32) return conv1d_cl_split16_narrow(a, stream);
-  SD_CHECK_ARG(a->w_dtype == SD_DT_SPLIT16 && a->x_dtype == SD_DT_SPLIT16 && a->y_dtype == SD_DT_F32,
-               "sd_conv1d_cl_split16: x and w must be split-packed (SD_DT_SPLIT16), y f32 (got %d/%d/%d)", a->x_dtype, a->w_dtype, a->y_dtype);
+  SD_CHECK_ARG(a->w_dtype == SD_DT_SPLIT16 && a->x_dtype == SD_DT_SPLIT16 && (a->y_dtype == SD_DT_F32 || a->y_dtype == SD_DT_SPLIT16),
+               "sd_conv1d_cl_split16: x and w must be split-packed (SD_DT_SPLIT16), y f32 or SD_DT_SPLIT16 (got %d/%d/%d)", a->x_dtype, a->w_dtype, a->y_dtype);
   SD_CHECK_ARG(a->M > 0 && a->T > 0 && a->M % a->T == 0, "sd_conv1d_cl_split16: M=%d must be a positive multiple of T=%d", a->M, a->T);
   SD_CHECK_ARG(a->cin > 0 && a->cin_pad >= a->cin && a->cin_pad % 32 == 0, "sd_conv1d_cl_split16: cin=%d cin_pad=%d (a multiple of 32)", a->cin, a->cin_pad);
   SD_CHECK_ARG(a->cout > 0, "sd_conv1d_cl_split16: cout=%d", a->cout);
@@ -1279,6 +1279,10 @@ extern "C" int sd_conv1d_cl_split16(const sd_conv_args* a, sd_stream_t stream_) 
   k.cin = 2 * a->cin_pad; k.cin_pad = 2 * a->cin_pad;
   k.x_dtype = SD_DT_F16; k.w_dtype = SD_DT_F16;
   const bool plain = vec && (a->act == SD_ACT_RELU || a->act == SD_ACT_NONE) && a->act2 == SD_ACT_NONE && !a->bias_per_seg && !a->tee;
+  if (a->y_dtype == SD_DT_SPLIT16) {    // y as split halves: the LDS-staged epilogue's store phase (the register epilogue writes f32 only)
+    SD_CHECK_ARG(vec && a->ldo % 32 == 0 && !a->colstat, "sd_conv1d_cl_split16: an SD_DT_SPLIT16 output needs ldo %% 32 == 0, aligned slices and no column statistics");
+    return launch_t256<float, false, true>(&k, vec, stream);
+  }
   if (plain) return launch_t256<float, true, true>(&k, vec, stream);
   return launch_t256<float, false, true>(&k, vec, stream);
 }

@@ -35,6 +35,7 @@ struct Buffers {
   void *x0, *r, *t2, *xcat, *h, *s0, *s1, *a1, *e;   // activation dtype (e = attention logits)
   void* xs;                                            // split16 mode: the SD_DT_SPLIT16 copy of a wide conv's input (pack scratch)
   void* xcs;                                           // split16 mode: SD_DT_SPLIT16 twin of xcat, written by the SE scale + residual kernel
+  void* x0s;                                           // split16 mode: the stem's output as SD_DT_SPLIT16 (block 1's tdnn1 input and shortcut)
   void* rs;                                            // split16 mode: the Res2Net output r as SD_DT_SPLIT16 (tdnn2's input), written by the narrow convs
   void* wpk; size_t wpk_bytes;                        // Res2Net chain weights in fragment order (f16 path)
   float *semean, *seh, *gate, *stats, *gbias, *pooled;
@@ -69,6 +70,7 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.wpk = c.take(b.wpk_bytes, 1);
   b.xs = (w->split16 == 1 && act_dtype == SD_DT_F32) ? c.take(M * (size_t)((Cm + 31) / 32 * 32), 4) : nullptr;
   b.xcs = (w->split16 == 1 && act_dtype == SD_DT_F32 && Cm % 32 == 0 && C % 32 == 0) ? c.take(M * (size_t)Cm, 4) : nullptr;
+  b.x0s = (w->split16 == 1 && act_dtype == SD_DT_F32 && C % 32 == 0) ? c.take(M * (size_t)C, 4) : nullptr;
   b.rs = (w->split16 == 1 && act_dtype == SD_DT_F32 && C % 32 == 0 && (C / w->res2_scale) % 32 == 0) ? c.take(M * (size_t)C, 4) : nullptr;
   b.a1 = b.x0;    // block-0 output is dead once block 1 has consumed it
   b.e = b.xcat;
@@ -157,11 +159,13 @@ bool wide_goes_narrow(const sd_layer& l, int M) {
 
 // twin / twin_ld: an SD_DT_SPLIT16 copy of a.x that already exists (same value columns a.a_col0 .. of rows of twin_ld value columns)
 int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, sd_stream_t stream, const void* twin = nullptr, int twin_ld = 0) {
-  if (!(split && l.w_split && xs && a.x_dtype == SD_DT_F32 && a.y_dtype == SD_DT_F32 && !(a.tee && a.tee_add) &&
-        !(a.colstat && a.T < 128)))
+  if (!(split && l.w_split && xs && a.x_dtype == SD_DT_F32 && (a.y_dtype == SD_DT_F32 || a.y_dtype == SD_DT_SPLIT16) && !(a.tee && a.tee_add) &&
+        !(a.colstat && a.T < 128))) {
+    if (a.y_dtype == SD_DT_SPLIT16) return sd_set_error(SD_ERR_UNSUPPORTED, "sd_ecapa_forward: a split output needs the split wide kernel");
     return run_conv(a, stream);
+  }
   const int cp = (l.cin + 31) / 32 * 32;
-  if (wide_goes_narrow(l, a.M) && !a.colstat && l.cin % 4 == 0 && a.lda % 4 == 0 && a.a_col0 % 4 == 0) {
+  if (a.y_dtype != SD_DT_SPLIT16 && wide_goes_narrow(l, a.M) && !a.colstat && l.cin % 4 == 0 && a.lda % 4 == 0 && a.a_col0 % 4 == 0) {
     a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = cp;           // f32 x stays: split while staged; the folded 2^s
     a.bias = l.bias_split; a.scale = l.scale_split; a.w_scale_inv = 0.f;    // form of bias / scale serves this kernel too
     return sd_conv1d_cl_split16(&a, stream);
@@ -208,6 +212,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     const char* e = sd_experiment_env("SD_COLSTAT");
     return !(e && e[0] == '0');
   }();
+  bool x0_split = false;                                 // the stem's output exists as SD_DT_SPLIT16 only (b.x0s)
   // block 0: TDNNBlock(n_mels -> C, k=5) on the f32 features.  f16: the features are rounded to f16 once (the
   // operand precision of that path anyway; t2 is free here), which lets the stem run on the LDS-DMA kernel of the
   // wide layers (-0.75 ms per 5000 segments: 106.6 -> 108.3 k segments/s).  SD_STEM_CAST=0: A/B switch.
@@ -220,10 +225,18 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       x = b.t2; xdt = SD_DT_F16;
     }
     sd_conv_args a = conv_of(w->block0, x, xdt, w->n_mels, 0, b.x0, dt, C, 0, M, T, SD_ACT_RELU);
+    // f32-split16x3, wide layers split: both readers of the stem's output (block 1's tdnn1 and its shortcut) take SD_DT_SPLIT16, so the
+    // stem writes that form and nothing else (no f32 tensor, no pack pass) -- unless a small launch sends tdnn1 to the narrow kernel
+    x0_split = wsplit && b.x0s && b.xcs && w->block0.w_split && w->blocks[0].tdnn1.w_split && !wide_goes_narrow(w->block0, M) &&
+               !wide_goes_narrow(w->blocks[0].tdnn1, M);
+    if (x0_split) { a.y = b.x0s; a.y_dtype = SD_DT_SPLIT16; }
     SD_TRY(run_wide(w->block0, a, wsplit, b.xs, stream));
   }
   const void* xin = b.x0; int ldin = C, colin = 0;
-  bool res_is_twin = false;                              // the current block input's f32 form was not written (read its SD_DT_SPLIT16 copy)
+  // where the current block input exists as SD_DT_SPLIT16 (null: it does not), and whether its f32 form was skipped
+  const void* in_sp = x0_split ? b.x0s : nullptr;
+  int in_sp_ld = C, in_sp_col = 0;
+  bool res_is_twin = x0_split;
   for (int i = 0; i < w->n_blocks; ++i) {
     const sd_se_res2_block& blk = w->blocks[i];
     // Res2Net chain: y_j = TDNN_j(c_j + y_{j-1}), written over chunk j of r.  f16: one kernel per block keeps the
@@ -241,7 +254,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       sd_conv_args a = conv_of(blk.tdnn1, xin, dt, ldin, colin, b.r, dt, C, 0, M, T, SD_ACT_RELU);
       if (!chain) { a.tee = b.s0; a.ldt = chunk; a.tee_lo = chunk; a.tee_hi = 2 * chunk; }
       // (blocks 2..: the input is a slice of xcat, whose split twin the previous block's SE kernel has written)
-      SD_TRY(run_wide(blk.tdnn1, a, wsplit, b.xs, stream, (i > 0 && xin == b.xcat) ? b.xcs : nullptr, Cm));
+      SD_TRY(run_wide(blk.tdnn1, a, wsplit, b.xs, stream, in_sp, in_sp_ld));
     }
     if (chain) {
       SD_TRY(sd_res2net_chain_f16(b.r, C, B, T, blk.res2, w->res2_scale - 1, b.wpk, b.wpk_bytes, stream));
@@ -291,11 +304,12 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       const bool next_reads_f32 = i + 1 < w->n_blocks && wide_goes_narrow(w->blocks[i + 1].tdnn1, M);
       const bool skip_f32 = twin && w->mfa.w_split && !wide_goes_narrow(w->mfa, M) && !next_reads_f32 &&
                             (i + 1 >= w->n_blocks || w->blocks[i + 1].tdnn1.w_split);
-      const bool res_twin = twin && i > 0 && res_is_twin;
+      const bool res_twin = twin && in_sp != nullptr && res_is_twin;
       SD_TRY(sd_se_scale_residual_split(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, dt,
                                         twin ? b.xcs : nullptr, Cm, i * C, stream,
-                                        res_twin ? b.xcs : nullptr, Cm, (i - 1) * C, skip_f32 ? 0 : 1));
+                                        res_twin ? in_sp : nullptr, in_sp_ld, in_sp_col, skip_f32 ? 0 : 1));
       res_is_twin = skip_f32;                            // the next block's shortcut exists only as the split copy
+      in_sp = twin ? b.xcs : nullptr; in_sp_ld = Cm; in_sp_col = i * C;
     }
     xin = b.xcat; ldin = Cm; colin = i * C;
   }
