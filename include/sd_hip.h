@@ -184,6 +184,9 @@ int sd_conv1d_cl_f16(const sd_conv_args* args, sd_stream_t stream);
  * kernel that splits the activations while it stages them (no pack pass, any row slice, the full tee / tee_add
  * epilogue, per-segment bias; no colstat) and multiplies the accumulators by w_scale_inv = 2^-s instead of folding
  * the weight scale into bias / scale: the Res2Net convs and the attention TDNN of the f32-split16x3 mode.
+ * y may be SD_DT_SPLIT16 instead of f32 (y_dtype; ldo, o_col0 in VALUE columns, ldo % 32 == 0, aligned slices, no colstat): the
+ * result leaves as split halves, bit for bit what sd_split16_pack_f32 would make of the f32 result, for a consumer that is another
+ * split conv (the narrow form, and the wide form through its LDS-staged epilogue); the tee copy stays f32.
  * Domain: |x| <= 65504 (larger values are clamped when packed / staged). */
 int sd_conv1d_cl_split16(const sd_conv_args* args, sd_stream_t stream);
 /* f32 [M][ldx] columns [col0, col0 + C), each multiplied by `mul` (a power of two: exact; 1 for activations) ->
