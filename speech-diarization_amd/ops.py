@@ -152,10 +152,10 @@ def conv1d_cl_split16(x: torch.Tensor, w_split: torch.Tensor, w_shift: int, T: i
     a.y_dtype = N.SD_DT_F32
     a.y, a.ldo, a.o_col0 = out.data_ptr(), out.stride(0), o_col0
     if out_split is not None:
-        # narrow kernel only: y leaves as SD_DT_SPLIT16 rows (f16 [M, 2 * ld], ld VALUE columns, a multiple of 32) instead of f32 --
+        # y leaves as SD_DT_SPLIT16 rows (f16 [M, 2 * ld], ld VALUE columns, a multiple of 32) instead of f32 --
         # bit for bit what split16_pack would make of the f32 result; `out` is then not written
-        if not narrow or out_split.dtype != torch.float16 or out_split.stride(1) != 1 or out_split.shape[1] % 64:
-            raise TypeError("out_split: f16 [M, 2 * ld] with ld % 32 == 0, narrow kernel only")
+        if out_split.dtype != torch.float16 or out_split.stride(1) != 1 or out_split.shape[1] % 64 or colstat is not None:
+            raise TypeError("out_split: f16 [M, 2 * ld] with ld % 32 == 0, no colstat")
         _need_cuda(out_split)
         a.y_dtype = N.SD_DT_SPLIT16
         a.y, a.ldo = out_split.data_ptr(), out_split.shape[1] // 2

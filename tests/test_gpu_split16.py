@@ -201,6 +201,23 @@ def test_narrow_split16_conv_writes_split_output(dev):
     assert torch.equal(tee2, tee32)
 
 
+@pytest.mark.parametrize("cin,cout,taps,B,T", [(80, 1024, 5, 3, 201), (256, 512, 1, 2, 150)])
+def test_wide_split16_conv_writes_split_output(dev, cin, cout, taps, B, T):
+    """The 256x256 split kernel with y as SD_DT_SPLIT16 rows (the stem of the f32-split16x3 schedule): bit for bit the pack of its f32
+    result (which comes from the register epilogue, the split form from the LDS-staged one), incl. a tile that hangs over row M."""
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B * T, cin, generator=g).to(dev)
+    w = torch.randn(cout, cin, taps, generator=g) / np.sqrt(cin * taps)
+    bias, scale, shift = torch.randn(cout, generator=g).to(dev), (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+    ws, s = ops.pack_weight_split16(w, dev)
+    kw = dict(cin=cin, bias=bias, act="relu", scale=scale, shift=shift)
+    y32 = ops.conv1d_cl_split16(x, ws, s, T, **kw)
+    ysp = torch.zeros((B * T, 2 * cout), device=dev, dtype=torch.float16)
+    ops.conv1d_cl_split16(x, ws, s, T, out=torch.zeros_like(y32), out_split=ysp, **kw)
+    assert torch.equal(ysp, ops.split16_pack(y32, 0, cout))
+
+
 @pytest.mark.parametrize("B,n", [(4, 32000), (5, 16000), (2, 100000), (3, 9600)])
 def test_ecapa_split16_full_geometry_matches_oracle(dev, B, n):
     """The exact-f32 path's full-geometry test (tests/test_gpu_fbank_ecapa.py) with the SAME bars, on the split16x3 engine;
