@@ -263,6 +263,25 @@ def test_ecapa_narrow_split_mode_matches_oracle(dev, B, n):
         EmbeddingEngine(sd, dev, precision="f32x")
 
 
+def test_ecapa_split16_exchange_path_matches_oracle(dev):
+    """44 segments = 8844 rows: just past the small-launch routing (<= 8192 rows send the C-wide layers to the 128x128 kernels), so the
+    256x256 split kernels run and the layers exchange SD_DT_SPLIT16 tensors instead of f32 ones (the stem's output, the Res2Net output
+    r, the block outputs: no f32 copy, no pack pass).  Same bars against the float64 oracle as the exact-f32 path; a batch of 4
+    (under the default routing: everything on the narrow kernels, f32 tensors) must agree with it to f32 rounding."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    wav = synth.synthetic_segments(3, 44, 32000)
+    eng = EmbeddingEngine(sd, dev, precision="f32s")
+    big = eng.embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    small = eng.embed(torch.from_numpy(wav[:4]).to(dev)).cpu().numpy()
+    ref = pipeline_ref.encode_batch_ref(sd, wav[:6], torch.float64)
+    cd = _cos_dist(big[:6], ref)
+    assert cd.max() < 1e-5 and np.abs(big[:6] - ref).max() < 1e-3 * np.abs(ref).max()
+    assert _cos_dist(big[:4], small).max() < 1e-9          # (another schedule under the default routing, the same one when the fixture forces the big tiles)
+
+
 def test_split16_identical_clusters_and_properties_at_full_size(dev):
     """north_star's 'identical cluster assignments' for the split16x3 engine (vs the exact-f32 engine and the CPU oracle,
     C = 1024), and the configs[1] batch (5000 segments through the 256x256 kernel at full occupancy): finite, run-to-run
