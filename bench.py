@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--segments", type=int, default=10000, help="segments per rank per step")
-    ap.add_argument("--micro-batch", type=int, default=5000)
+    ap.add_argument("--micro-batch", type=int, default=10000, help="segments per fbank + ECAPA launch (round 3: 10 000 = the whole step in one forward; 5 000 before: -1 %)")
     ap.add_argument("--precision", choices=["f32", "f16", "f32s", "f32ns"], default="f32",
                     help="f32: exact f32 MFMA (configs[1], the headline). f16: f16 operands / f32 accumulate (configs[4]). "
                          "f32s: f32-split16x3 (every frame-level contraction as three f16 MFMA products per value pair, f32-level accuracy). "
