@@ -2,6 +2,7 @@
 """Headline benchmark: segment-embeddings/sec on synthetic 2 s @ 16 kHz segments.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 3 --warmup 1      (starts the next line as a child process: speech_diarization_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -125,8 +126,51 @@ def load_traffic():
     return load_profile_json("traffic.json")
 
 
+def der_vs_cpu(state_dict, dev, precision):
+    """The metric's second half (BASELINE.json: "...; DER vs CPU ref"; BASELINE.md §3: label agreement after clustering,
+    DER of the GPU RTTM against the CPU RTTM): BASELINE.json configs[0]'s recording (60 s, 2 synthetic speakers, seed 0)
+    through the product entry `diarization_baseline.diarize_audio` [REF diarization_baseline.py:236-266] twice - once on
+    the HIP path (windows read in place, cosine affinity on the device), once with the CPU oracle encoder injected -
+    at the bench's full geometry and weights.  Outside the timed region; the oracle is the checker, not the product."""
+    from oracle.ecapa_ref import EcapaRef
+    from oracle.pipeline_ref import encode_batch_ref
+    from speech_diarization_amd import diarization_baseline as db, rttm, speech_encode, synth
+    conv = synth.synthetic_conversation(60.0, 2, seed=0)
+    audio = {"waveform": conv.wav, "sample_rate": conv.sr, "uri": "config0"}
+    enc = speech_encode.HipEcapaEncoder(state_dict, dev, max_batch=512, precision=precision)
+    keep = speech_encode.using_ecapa_encoder
+    speech_encode.using_ecapa_encoder = lambda device="cuda": enc
+    try:
+        t0 = time.perf_counter()
+        seg_g, det_g = db.diarize_audio(audio, 0.35, 0.1, 2, 6, return_details=True)
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t0
+    finally:
+        speech_encode.using_ecapa_encoder = keep
+    torch.set_num_threads(usable_cores())
+    net = EcapaRef(state_dict, torch.float32)
+    cpu = lambda wavs: encode_batch_ref(state_dict, np.asarray(wavs, np.float32), torch.float32, net).astype(np.float32)  # noqa: E731
+    t0 = time.perf_counter()
+    seg_c, det_c = db.diarize_audio(audio, 0.35, 0.1, 2, 6, encoder=cpu, return_details=True)
+    t_cpu = time.perf_counter() - t0
+    g, c = det_g["embeddings"].astype(np.float64), det_c["embeddings"].astype(np.float64)
+    cosd = 1.0 - (g * c).sum(1) / (np.linalg.norm(g, axis=1) * np.linalg.norm(c, axis=1))
+    truth = [(s, e, f"T{k}") for s, e, k in conv.turns]
+    return {"der_vs_cpu": float(rttm.der(seg_c, seg_g)), "labels_identical": bool(np.array_equal(det_g["labels"], det_c["labels"])),
+            "rttm_turns_identical": seg_g == seg_c, "windows": int(len(det_g["labels"])), "speakers": int(len({k for _, _, k in seg_g})),
+            "max_cosine_distance": float(cosd.max()), "der_vs_ground_truth": float(rttm.der(truth, seg_g)),
+            "workload": "configs[0]: 60 s 2-speaker synthetic recording (seed 0), diarize_audio, 2 s windows / 0.25 s hop, spectral clustering, "
+                        "full ECAPA geometry with the bench's weights; GPU = HIP path at `dtype`, CPU = torch-f32 oracle encoder injected",
+            "gpu_wall_s": t_gpu, "cpu_wall_s": t_cpu}
+
+
 def main():
     args = parse()
+    # `python bench.py --gpus N` from a plain shell: the parent (which has not touched the GPU: importing torch does not)
+    # starts the N ranks under torch.distributed.run as a child process and relays its output and exit code
+    from speech_diarization_amd import launch
+    if launch.needs_self_launch(args.gpus):
+        raise SystemExit(launch.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     from speech_diarization_amd import _native, ops, synth
     from speech_diarization_amd import dist as sdist
     from speech_diarization_amd.engine import EmbeddingEngine
@@ -146,6 +190,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     _native.load()
+    # "did the collective see N ranks": a sum of ones over the process group, on the device for RCCL
+    ranks_seen = 1
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if ranks_seen != world:
+            raise SystemExit(f"all_reduce saw {ranks_seen} ranks, WORLD_SIZE={world}")
 
     state_dict = synth.make_ecapa_state_dict(1234)
     engine = EmbeddingEngine(state_dict, dev, max_batch=args.micro_batch, precision=args.precision)
@@ -311,6 +363,7 @@ def main():
             "unit": "segments/s",
             "n_gpus": world if backend == "nccl" else min(world, n_dev),    # a gloo rehearsal may put several ranks on one card
             "ranks": world,
+            "n_ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -391,6 +444,9 @@ def main():
                                                emb16 if extra_f16 is not None else (emb if args.precision == "f16" else None))
             if extra_split is not None and "max_cosine_distance_vs_gpu" in out["cpu_baseline"]:
                 out["cpu_baseline"]["note_split16x3"] = "the f32-split16x3 embeddings sit max_cosine_distance_vs_f32_path from the exact-f32 ones"
+            out["der"] = der_vs_cpu(state_dict, dev, args.precision)
+            out["der_vs_cpu"] = out["der"]["der_vs_cpu"]
+            out["labels_identical"] = out["der"]["labels_identical"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -62,6 +62,36 @@ def test_config1_full_size_properties(dev):
     print(f"config 1 full size: f16 vs f32 max cosine distance {float(cos16.max()):.2e}, vs float64 oracle {cd.max():.2e}")
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
+def test_config1_at_the_bench_launch_shape(dev, precision):
+    """`bench.py`'s step since round 3: ONE forward of 10 000 segments (max_batch = micro-batch = 10 000; ~105 GB of
+    workspace at f32, ~150 GB with the split copies of f32-split16x3), on the bench's own input stream.  Five rows
+    against the float64 oracle (< 1e-5 cosine distance), the same launch twice bitwise equal, and the rows the launch
+    shares with two launches of 5 000 equal to f32 rounding."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    n = 10000
+    wav = synth.synthetic_segments_device(0, n, 32000, dev, std=0.1)
+    eng = EmbeddingEngine(sd, dev, max_batch=n, precision=precision)
+    emb = eng.embed(wav)
+    assert emb.shape == (n, 192) and bool(torch.isfinite(emb).all())
+    assert torch.equal(eng.embed(wav), emb)                  # run-to-run bitwise at this launch size
+    idx = torch.tensor([0, 4999, 5000, 7777, 9999], device=dev)
+    ref = pipeline_ref.encode_batch_ref(sd, wav[idx].cpu().numpy(), torch.float64)
+    e = emb[idx].cpu().numpy().astype(np.float64)
+    cd = 1.0 - (e * ref).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(ref, axis=1))
+    assert cd.max() < 1e-5, cd
+    del eng
+    torch.cuda.empty_cache()
+    half = EmbeddingEngine(sd, dev, max_batch=5000, precision=precision)
+    two = torch.cat([half.embed(wav[:5000]), half.embed(wav[5000:])])
+    cos2 = 1.0 - torch.nn.functional.cosine_similarity(two.double(), emb.double(), dim=1)
+    assert float(cos2.max()) < 1e-9
+    print(f"bench launch shape, {precision}: vs float64 oracle {cd.max():.2e}, vs 2 x 5000 {float(cos2.max()):.2e}")
+
+
 def test_config2_sharded_meeting_matches_unsharded_and_cpu(dev):
     """10 min, 8 voices: windows are embedded (a) in one piece, (b) as 8 round-robin shards that are
     gathered and de-interleaved (the W = 8 layout, executed rank by rank on this one GPU).  Rows are

@@ -2,8 +2,11 @@
 """BASELINE.json configs[2] as a launchable job: one process per GPU, VAD windows sharded round-robin,
 ONE RCCL all-gather of the 192-d embeddings, clustering, RTTM from rank 0.
 
+    python tools/diarize_sharded.py meeting.wav --rttm meeting.rttm --gpus 8
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
         tools/diarize_sharded.py meeting.wav --rttm meeting.rttm
+
+The first form starts the second as a child process (the parent never touches the GPU: `launch.self_launch`).
 
 Same entry point and output as the single-process call [REF diarization_baseline.py:236-266]; with
 WORLD_SIZE unset it IS the single-process call.  --synthetic N writes an N-second 8-speaker test meeting first.
@@ -25,7 +28,11 @@ def main():
     ap.add_argument("--min-speakers", type=int, default=2)
     ap.add_argument("--max-speakers", type=int, default=8)
     ap.add_argument("--clustering", default="spectral")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start (one per GPU) when not already under torchrun")
     a = ap.parse_args()
+    from speech_diarization_amd import launch
+    if launch.needs_self_launch(a.gpus):
+        raise SystemExit(launch.self_launch(os.path.abspath(__file__), sys.argv[1:], a.gpus))
     import torch
     import torch.distributed as tdist
     from speech_diarization_amd import audio_io, diarization_baseline as db, dist, synth
