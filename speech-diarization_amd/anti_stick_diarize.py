@@ -4,7 +4,8 @@ Function names, signatures and results follow the reference's `anti_stick_diariz
 (`Segment`, `scd_split_segments` [REF :78-127], `embed_segments` [REF :130-172],
 `conservative_merge` [REF :273-330], `speaker_centroids` [REF :333-349],
 `cluster_hdbscan` / `cluster_hdbscan_two_stage` [REF :175-270], `_get_speech_windows` [REF :352-367], `frame_reassign` [REF :390-460], `merge_adjacent`
-[REF :464-475], `diarize` [REF :493-560]).  What changes is where the work runs:
+[REF :464-475], `diar_read_audio` / `loudness_normalize` [REF :29-61], `diarize` [REF :493-560], `main` [REF :563-604]).
+What changes is where the work runs:
 
 * every function that embeds takes an optional `encode` callable (`wavs[B, n] -> [B, 192]`);
   the default is the HIP encoder (`speech_encode.ecapa_encode_batch`).  Tests inject a
@@ -23,7 +24,9 @@ Known defects of the reference that this module does NOT reproduce by default
 from __future__ import annotations
 
 import math
+import warnings
 from dataclasses import dataclass
+from pathlib import Path
 from typing import Callable
 
 import numpy as np
@@ -41,6 +44,60 @@ class Segment:
     end: float
     spk: int | None = None
     score: float | None = None
+
+
+# --------------------------------------------------------------------------- loading + conditioning
+
+def loudness_normalize(y: np.ndarray, sr: int, target_lufs: float = -18.0) -> np.ndarray:
+    """Integrated-loudness normalisation to `target_lufs`, clipped to +-0.99 [REF anti_stick_diarize.py:53-61].  The meter
+    is the reference's own dependency (`pyloudnorm`, ITU-R BS.1770); it is not restated here: without it this raises."""
+    import pyloudnorm as pyln
+    meter = pyln.Meter(sr)
+    y = pyln.normalize.loudness(y, meter.integrated_loudness(y), target_lufs)
+    return np.clip(y, -0.99, 0.99)
+
+
+_warned_no_meter = False
+
+
+def diar_read_audio(path_wav, sr: int = 16000, lufs: float | None = -18.0):
+    """-> (conditioned mono float32 signal, sr) [REF anti_stick_diarize.py:29-50]: a path is read and resampled
+    (`audio_io.read_audio`: WAV; polyphase resampling where the reference uses librosa's kaiser_fast), an
+    `(array, orig_sr)` tuple is transposed when it is [n, <= 2], resampled and mixed down; then loudness normalisation
+    when `lufs` is not None AND a loudness meter is importable (otherwise the `lufs=None` behaviour, with ONE warning per
+    process), DC removal, and pre-emphasis 0.97 with librosa's initial state (`zi = 2 x[0] - x[1]` handed to `lfilter`
+    as it is [UPSTREAM-RECALLED librosa.effects.preemphasis], i.e. y[0] = 3 x[0] - x[1], y[n] = x[n] - 0.97 x[n-1])."""
+    global _warned_no_meter
+    from . import audio_io
+    if isinstance(path_wav, (str, Path)):
+        wav, sr = audio_io.read_audio(path_wav, sr=sr, mono=True)
+    else:
+        wav, orig_sr = path_wav
+        wav = np.asarray(wav, dtype=np.float32)
+        if wav.ndim == 2 and wav.shape[1] <= 2:
+            wav = wav.T
+        if orig_sr != sr:
+            from scipy.signal import resample_poly
+            g = math.gcd(int(orig_sr), int(sr))
+            wav = resample_poly(wav, sr // g, int(orig_sr) // g, axis=-1).astype(np.float32)
+        if wav.ndim == 2:
+            wav = wav.mean(axis=0)
+    if lufs is not None:
+        try:
+            wav = loudness_normalize(wav, sr, target_lufs=lufs)
+        except ImportError:
+            if not _warned_no_meter:
+                _warned_no_meter = True
+                warnings.warn("pyloudnorm is not installed: target_lufs is ignored (signal conditioned as with target_lufs=None)",
+                              RuntimeWarning, stacklevel=2)
+    wav = np.asarray(wav, dtype=np.float32)
+    if wav.size == 0:
+        return wav, sr
+    wav = wav - np.mean(wav)
+    out = np.empty_like(wav)
+    out[1:] = wav[1:] - np.float32(0.97) * wav[:-1]
+    out[0] = wav[0] + (2.0 * wav[0] - (wav[1] if wav.size > 1 else wav[0]))
+    return out.astype(np.float32), sr
 
 
 def _default_encode() -> Encoder:
@@ -298,22 +355,30 @@ def _assign_windows_gpu(y: np.ndarray, starts: np.ndarray, win_samples: int, c_m
 
 # --------------------------------------------------------------------------- orchestration
 
-def diarize(wav: np.ndarray, sr: int = 16000, vad_on_thr: float = 0.6, vad_off_thr: float = 0.4, min_speech_ms: float = 250,
-            min_silence_ms: float = 100, speech_pad_ms: float = 70.0, morph_open_ms: float = 80.0, morph_close_ms: float = 40.0,
-            scd_win_ms: float = 1000.0, scd_hop_ms: float = 200, scd_thr: float = 1.50, merge_max_gap_s: float = 0.5,
-            merge_max_speech_s: float = 30.0, merge_mincos: float = 0.8, reseg: int = 1, cluster_cos: float = 0.70,
-            encode: Encoder | None = None, vad_segments: Callable | None = None,
+def diarize(wav_path, sr: int = 16000, target_lufs: float = -18.0, vad_on_thr: float = 0.6, vad_off_thr: float = 0.4,
+            min_speech_ms: float = 250, min_silence_ms: float = 100, speech_pad_ms: float = 70.0, morph_open_ms: float = 80.0,
+            morph_close_ms: float = 40.0, scd_win_ms: float = 1000.0, scd_hop_ms: float = 200, scd_thr: float = 1.50,
+            merge_max_gap_s: float = 0.5, merge_max_speech_s: float = 30.0, merge_mincos: float = 0.8, reseg: int = 1, *,
+            cluster_cos: float = 0.70, encode: Encoder | None = None, vad_segments: Callable | None = None,
             compat_reference_bugs: bool = False, clusterer: str | Callable = "hdbscan_two_stage") -> list[Segment]:
     """VAD -> SCD split -> embed -> cluster -> conservative merge -> re-embed -> frame reassignment ->
-    merge_adjacent, the stage order of [REF anti_stick_diarize.py:493-560] on an already loaded,
-    conditioned 16 kHz mono float32 signal.
+    merge_adjacent: the stage order and the positional parameters of [REF anti_stick_diarize.py:493-511] (the 17
+    parameters up to `reseg`, same order and defaults; what this build adds is keyword-only).
+
+    `wav_path`: a path or an `(array, sample_rate)` tuple, loaded and conditioned by `diar_read_audio(wav_path, sr,
+    lufs=target_lufs)` as in the reference [REF :512]; additionally a bare 1-d numpy array, taken as an already loaded and
+    conditioned mono signal at `sr` (no loudness / DC / pre-emphasis step).
 
     `clusterer` selects what sits inside the reference's `cluster_hdbscan_two_stage(embs, min_cluster_size=2)`
     [REF :536]: "hdbscan_two_stage" (default: the two-stage glue over `cluster.default_hdbscan_factory`),
     "ahc" (the same glue with average-linkage AHC cut at `cluster_cos` injected as the clusterer), "ahc_affinity"
     (single-stage AHC on the GPU cosine affinity), or a `clusterer_factory(**kwargs)` callable."""
     from . import cluster
-    y = np.ascontiguousarray(wav, dtype=np.float32)
+    if isinstance(wav_path, np.ndarray):
+        y = np.ascontiguousarray(wav_path, dtype=np.float32)
+    else:
+        y, sr = diar_read_audio(wav_path, sr, lufs=target_lufs)
+        y = np.ascontiguousarray(y, dtype=np.float32)
     vad_fn = vad_segments or silero_vad_segments
     speech_t = vad_fn(y, sr, on_threshold=vad_on_thr, off_threshold=vad_off_thr, min_speech_ms=min_speech_ms,
                       min_silence_ms=min_silence_ms, speech_pad_ms=speech_pad_ms, morph_open_ms=morph_open_ms,
@@ -340,6 +405,22 @@ def diarize(wav: np.ndarray, sr: int = 16000, vad_on_thr: float = 0.6, vad_off_t
     embs3 = embed_segments(y, sr, speech3, encode=encode)
     speech4 = frame_reassign(y, sr, speech, speech3, embs3, smooth_step=0.10, win=1.0, encode=encode) if reseg else speech3
     return merge_adjacent(speech4, gap=merge_max_gap_s)
+
+
+def main(wav_path: str, sr: int = 16000, target_lufs: float = -18.0, vad_thr: float = 0.55, min_speech: float = 0.15,
+         min_silence: float = 0.10, speech_pad: float = 0.04, morph_bridge_ms: float = 80.0, scd_win: float = 0.8,
+         scd_step: float = 0.2, scd_thr: float = 1.2, cluster_cos: float = 0.65, merge_gap: float = 0.25,
+         merge_maxturn: float = 10.0, merge_mincos: float = 0.7, reseg: int = 1):
+    """The CLI entry of [REF anti_stick_diarize.py:563-604], parameter for parameter.  The reference forwards its 16
+    arguments POSITIONALLY into `diarize`, whose parameter order does not match (`min_speech` seconds land in
+    `vad_off_thr`, `cluster_cos` in `scd_hop_ms`, ...: SURVEY.md Appendix B-2); the forwarding is kept as it is, so
+    the same command line gives the same call."""
+    final = diarize(wav_path, sr, target_lufs, vad_thr, min_speech, min_silence, speech_pad, morph_bridge_ms, scd_win,
+                    scd_step, scd_thr, cluster_cos, merge_gap, merge_maxturn, merge_mincos, reseg)
+    print(f"Segments:{len(final)}; Speakers:{len(set(s.spk for s in final))}")
+    for i, s in enumerate(final[:10], 1):
+        print(f"{i:02d}  {s.start:.2f}-{s.end:.2f}  SPK_{s.spk}")
+    return final
 
 
 def cluster_hdbscan(embs: np.ndarray, min_cluster_size: int = 2, clusterer_factory=None, use_gpu: bool = False) -> np.ndarray:

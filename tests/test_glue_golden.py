@@ -291,3 +291,47 @@ def test_diarize_with_a_single_segment_returns_one_speaker():
     assert len(segs) == 1 and segs[0].spk == 0 and (segs[0].start, segs[0].end) == (0.5, 1.4)
     segs = asd.diarize(y, vad_segments=lambda *a, **k: [(0.5, 1.4)], encode=encode, reseg=1)
     assert all(s.spk == 0 for s in segs)
+
+
+def test_diarize_accepts_the_reference_call_forms(tmp_path):
+    """[REF anti_stick_diarize.py:493-512]: first argument a path or an (array, sr) tuple, `target_lufs` third; the
+    loaded signal is conditioned by `diar_read_audio` (DC removal + 0.97 pre-emphasis; no loudness meter in this
+    image: one warning, `target_lufs=None` behaviour).  A bare array is taken as already conditioned."""
+    import warnings
+    from scipy.signal import lfilter
+    from speech_diarization_amd import audio_io
+    rng = np.random.default_rng(1)
+    x48 = (0.1 * rng.standard_normal((48000 * 2, 2)) + 0.02).astype(np.float32)        # [n, 2] at 48 kHz with a DC offset
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        y, sr = asd.diar_read_audio((x48, 48000), 16000, lufs=-18.0)
+        y_none, _ = asd.diar_read_audio((x48, 48000), 16000, lufs=None)
+    assert sr == 16000 and y.dtype == np.float32 and y.shape == (32000,) and np.array_equal(y, y_none)
+    from scipy.signal import resample_poly
+    m = resample_poly(x48.T, 1, 3, axis=-1).astype(np.float32).mean(axis=0)
+    m = m - m.mean()
+    want = lfilter([1.0, -0.97], [1.0], m.astype(np.float64), zi=[2.0 * m[0] - m[1]])[0]      # librosa's preemphasis
+    assert np.abs(y - want).max() < 1e-6
+    assert asd.diar_read_audio((np.zeros(0, np.float32), 16000), lufs=None)[0].size == 0
+    wav = tmp_path / "a.wav"
+    audio_io.write_wav16(wav, m, 16000)
+    got = {}
+
+    def vad_segments(sig, sr_, **kw):
+        got["y"], got["kw"] = sig, kw
+        return []
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        assert asd.diarize(str(wav), 16000, -18.0, 0.7, 0.3, vad_segments=vad_segments) == []
+    assert got["kw"]["on_threshold"] == 0.7 and got["kw"]["off_threshold"] == 0.3          # positional slots 4 and 5, as in the reference
+    assert got["y"].shape == (32000,) and abs(float(got["y"][5:].mean())) < 1e-3
+    p = np.round(m * 32767.0).clip(-32768, 32767) / 32768.0
+    p = p - p.mean()
+    assert np.abs(got["y"][1:] - (p[1:] - 0.97 * p[:-1])).max() < 1e-5                     # read from the file, then conditioned
+    asd.diarize((m, 16000), vad_segments=vad_segments, target_lufs=None)
+    assert np.abs(got["y"][1:] - (m[1:] - np.float32(0.97) * m[:-1])).max() < 1e-6
+    asd.diarize(m, vad_segments=vad_segments)                                              # bare array: untouched
+    assert np.array_equal(got["y"], m)
+    with pytest.raises(ImportError):
+        asd.loudness_normalize(m, 16000)
