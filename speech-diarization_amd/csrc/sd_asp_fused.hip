@@ -278,7 +278,7 @@ constexpr int SLD = AK + 8;   // LDS row stride of a split a1 plane in halfs (27
 template <int NT, bool SPLIT = false>   // 16-frame tiles: T <= 16 * NT
 __global__ __launch_bounds__(512, 2) void asp_attend_pool_f32_kernel(const float* __restrict__ a1, const float* __restrict__ wc,
                                                                      const float* __restrict__ h, int ldh, int Tn, int C, int cpb,
-                                                                     float eps, float* __restrict__ out) {
+                                                                     float eps, float* __restrict__ out, float wscale) {
   extern __shared__ __attribute__((aligned(16))) float sf[];   // [NT * 16][FLD]   (SPLIT: two planes of [NT * 16][SLD] halfs)
   const int cblocks = C / cpb;
   const int b = blockIdx.x / cblocks, cblk = blockIdx.x % cblocks;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void asp_attend_pool_f32_kernel(const float
       if constexpr (SPLIT) {
         h4 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+        for (int e = 0; e < 4; ++e) { const float c = sd_split16_clamp(v[e]); hi[e] = (_Float16)c; lo[e] = (_Float16)(c - (float)hi[e]); }
         *reinterpret_cast<h4*>(s_hi + row * SLD + q) = hi;
         *reinterpret_cast<h4*>(s_lo + row * SLD + q) = lo;
       } else {
@@ -330,13 +330,13 @@ __global__ __launch_bounds__(512, 2) void asp_attend_pool_f32_kernel(const float
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (SPLIT) {
-      constexpr float WS = 256.f;
+      const float WS = wscale;            // a power of two from the host: max |w| WS in [512, 1024) (sd_asp_attend_pool_dt alone: 2^8, clamped)
       h8 whi[4], wlo[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float w = WS * wf[2 * s4 + (e >> 2)][e & 3];
+          const float w = sd_split16_clamp(WS * wf[2 * s4 + (e >> 2)][e & 3]);
           whi[s4][e] = (_Float16)w;
           wlo[s4][e] = (_Float16)(w - (float)whi[s4][e]);
         }
@@ -456,13 +456,13 @@ __global__ __launch_bounds__(512, 2) void asp_attend_pool_f32_kernel(const float
 }
 
 template <int NT, bool SPLIT = false>
-int launch_f32(const void* a1, const void* wc, const void* h, int ldh, int B, int T, int C, float eps, float* out, hipStream_t s) {
+int launch_f32(const void* a1, const void* wc, const void* h, int ldh, int B, int T, int C, float eps, float* out, hipStream_t s, float wscale = 256.f) {
   auto kern = asp_attend_pool_f32_kernel<NT, SPLIT>;
   const size_t lds = SPLIT ? (size_t)2 * NT * 16 * SLD * sizeof(_Float16) : (size_t)NT * 16 * FLD * sizeof(float);
   const int cpb = C % 512 == 0 ? 512 : 256;
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * (C / cpb))), dim3(512), lds, s, static_cast<const float*>(a1),
-                     static_cast<const float*>(wc), static_cast<const float*>(h), ldh, T, C, cpb, eps, out);
+                     static_cast<const float*>(wc), static_cast<const float*>(h), ldh, T, C, cpb, eps, out, wscale);
   SD_CHECK_LAUNCH("asp_attend_pool_f32_kernel");
   return SD_OK;
 }
@@ -475,7 +475,16 @@ extern "C" int sd_asp_attend_pool_supported(int dtype, int T, int C, int att) {
 
 extern "C" int sd_asp_attend_pool_dt(const void* a1, const void* wc, const void* h, int dtype, int ldh, int B, int T, int C,
                                      int att, float eps, float* out, sd_stream_t stream) {
+  return sd_asp_attend_pool_scaled(a1, wc, h, dtype, ldh, B, T, C, att, eps, 256.f, out, stream);
+}
+
+// w_scale (SD_DT_SPLIT16 only): the power of two the f32 attention-conv weights are multiplied with before they are split into f16
+// halves; the forward passes the data-dependent 2^s of the layer (max |w| 2^s in [512, 1024), as every other split weight); the
+// public entry above passes 2^8, the right magnitude for trained ECAPA weights (|w| ~ 0.1), and values beyond the f16 range clamp.
+int sd_asp_attend_pool_scaled(const void* a1, const void* wc, const void* h, int dtype, int ldh, int B, int T, int C,
+                              int att, float eps, float w_scale, float* out, sd_stream_t stream) {
   SD_CHECK_ARG(a1 && wc && h && out, "sd_asp_attend_pool_dt: null pointer");
+  SD_CHECK_ARG(w_scale > 0.f, "sd_asp_attend_pool_dt: w_scale=%g", (double)w_scale);
   SD_CHECK_ARG(B >= 0 && (long)B * (C > 0 ? C : 1) < (1L << 31), "sd_asp_attend_pool_dt: B=%d", B);
   if (!sd_asp_attend_pool_supported(dtype, T, C, att))
     return sd_set_error(SD_ERR_UNSUPPORTED, "sd_asp_attend_pool_dt: dtype=%d T=%d C=%d att=%d not covered (att=128, C%%256==0, T<=256)",
@@ -485,10 +494,10 @@ extern "C" int sd_asp_attend_pool_dt(const void* a1, const void* wc, const void*
   if (B == 0) return SD_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == SD_DT_SPLIT16) {       // f32 tensors, the logits product as three f16 MFMA products per value pair (f32-split16x3 mode)
-    if (T <= 64) return launch_f32<4, true>(a1, wc, h, ldh, B, T, C, eps, out, s);
-    if (T <= 128) return launch_f32<8, true>(a1, wc, h, ldh, B, T, C, eps, out, s);
-    if (T <= 208) return launch_f32<13, true>(a1, wc, h, ldh, B, T, C, eps, out, s);
-    return launch_f32<16, true>(a1, wc, h, ldh, B, T, C, eps, out, s);
+    if (T <= 64) return launch_f32<4, true>(a1, wc, h, ldh, B, T, C, eps, out, s, w_scale);
+    if (T <= 128) return launch_f32<8, true>(a1, wc, h, ldh, B, T, C, eps, out, s, w_scale);
+    if (T <= 208) return launch_f32<13, true>(a1, wc, h, ldh, B, T, C, eps, out, s, w_scale);
+    return launch_f32<16, true>(a1, wc, h, ldh, B, T, C, eps, out, s, w_scale);
   }
   if (dtype == SD_DT_F32) {
     if (T <= 64) return launch_f32<4>(a1, wc, h, ldh, B, T, C, eps, out, s);

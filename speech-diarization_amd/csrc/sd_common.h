@@ -18,6 +18,8 @@ int sd_conv1d_cl_f32_symmetric(const sd_conv_args* a, sd_stream_t stream);   // 
 int sd_affinity_sym_f32(const float* xn, int ldx, int N, int groups, float* out, long ldo, sd_stream_t stream);                          // sd_affinity.hip
 int sd_affinity_sym_split16(const void* xs, int ldx, int N, int groups, float* out, long ldo, float alpha, sd_stream_t stream);   // sd_affinity.hip
 int sd_cast_f32_f16(const float* x, long n, void* y, sd_stream_t stream);           // sd_pool.hip
+int sd_asp_attend_pool_scaled(const void* a1, const void* wc, const void* h, int dtype, int ldh, int B, int T, int C, int att, float eps,
+                              float w_scale, float* out, sd_stream_t stream);         // sd_asp_fused.hip: sd_asp_attend_pool_dt with the split weights' 2^s
 int sd_se_scale_residual_split(const void* x, int ldx, const float* gate, const void* res, int ldr, int r_col0, void* y, int ldy, int y_col0,
                                int B, int T, int C, int dtype, void* ys, int lds, int s_col0, sd_stream_t stream,
                                const void* res_split, int ld_rs, int rs_col0, int write_y);   // sd_pool.hip
@@ -63,6 +65,14 @@ static inline const char* sd_experiment_env(const char* name) {
 }
 
 static inline bool sd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// The value an f32 activation / operand takes on its way into an SD_DT_SPLIT16 pair (hi = f16(w), lo = f16(w - hi)): clamped to the
+// f16 range, NaN kept (v_med3_f32 alone returns min3 of its operands for a NaN, i.e. -65504: a NaN would be laundered into a
+// finite value).  Every split site uses this, so a producer that writes split halves gives the bits sd_split16_pack_f32 would.
+__device__ __forceinline__ float sd_split16_clamp(float v) {
+  const float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  return v != v ? v : c;
+}
 
 __device__ __forceinline__ float sd_wave_max(float v) {
 #pragma unroll

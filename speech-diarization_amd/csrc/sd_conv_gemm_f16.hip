@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split16_n128_kernel(const sd
       h4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float w = __builtin_amdgcn_fmed3f(st.a[i][e], -65504.f, 65504.f);
+        const float w = sd_split16_clamp(st.a[i][e]);
         hi[e] = (_Float16)w;
         lo[e] = (_Float16)(w - (float)hi[e]);
       }
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(256) void split16_pack_kernel(const float* __restri
     h8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float w = v[e] != v[e] ? v[e] : __builtin_amdgcn_fmed3f(v[e] * mul, -65504.f, 65504.f);
+      const float w = sd_split16_clamp(v[e] * mul);
       hi[e] = (_Float16)w;
       lo[e] = (_Float16)(w - (float)hi[e]);
     }

@@ -152,20 +152,38 @@ int run_narrow(const sd_layer& l, sd_conv_args a, bool split, sd_stream_t stream
 // Small launches of the C-wide layers (measured, tools/probe_split16.py: 1024 -> 1024 at 32 segments 0.063 ms on the 128x128 split
 // kernel against 0.085 ms for pack + 256x256 kernel, 0.041 against 0.079 at 16; from 64 segments up, and for 3C -> 3C always, the
 // 256x256 kernel wins): at most 128 tiles of 256x256 and cout <= 1024 -> the narrow kernel, which has no column statistics.
-bool wide_goes_narrow(const sd_layer& l, int M) {
+// `narrow_tiles`: SD_TUNE_F16_NARROW_TILES (default 128), read ONCE per forward: the schedule decides up front which tensors exist
+// only as SD_DT_SPLIT16, so every evaluation inside one forward must see the same value whatever sd_set_tuning() does meanwhile.
+bool wide_goes_narrow(const sd_layer& l, int M, long narrow_tiles) {
   const long tiles = (long)((M + 255) / 256) * ((l.cout + 255) / 256);
-  return l.cout <= 1024 && tiles <= sd_f16_narrow_tiles().load(std::memory_order_relaxed);     // SD_TUNE_F16_NARROW_TILES (default 128)
+  return l.cout <= 1024 && tiles <= narrow_tiles;
 }
 
+// The wide kernel's packing: weights scaled by 2^s with the scale folded into bias_split / scale_split.  A wide-ROLE layer (stem,
+// tdnn1, tdnn2, MFA) of a small geometry (cout <= 256) may carry the NARROW packing instead (w_split + split_scale_inv, no folded
+// vectors): it then runs on the 128x128 split kernel with its own bias / scale, or on the exact kernel.
+bool wide_packed(const sd_layer& l) { return l.w_split && l.bias_split && l.scale_split; }
+
 // twin / twin_ld: an SD_DT_SPLIT16 copy of a.x that already exists (same value columns a.a_col0 .. of rows of twin_ld value columns)
-int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, sd_stream_t stream, const void* twin = nullptr, int twin_ld = 0) {
-  if (!(split && l.w_split && xs && a.x_dtype == SD_DT_F32 && (a.y_dtype == SD_DT_F32 || a.y_dtype == SD_DT_SPLIT16) && !(a.tee && a.tee_add) &&
+int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, long narrow_tiles, sd_stream_t stream, const void* twin = nullptr, int twin_ld = 0) {
+  const int cp = (l.cin + 31) / 32 * 32;
+  if (split && l.w_split && !wide_packed(l)) {
+    // narrow packing on a wide-role layer: the weights are scaled by 2^s and NOTHING else carries the scale, so the only split
+    // kernel that may take them is the 128x128 one with w_scale_inv (the layer's own bias / scale); otherwise exact f32
+    if (a.y_dtype == SD_DT_SPLIT16) return sd_set_error(SD_ERR_UNSUPPORTED, "sd_ecapa_forward: a split output needs the wide packing");
+    if (l.split_scale_inv > 0.f && a.x_dtype == SD_DT_F32 && a.y_dtype == SD_DT_F32 && !a.colstat && l.cin % 4 == 0 && a.lda % 4 == 0 &&
+        a.a_col0 % 4 == 0) {
+      a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = cp; a.w_scale_inv = l.split_scale_inv;
+      return sd_conv1d_cl_split16(&a, stream);
+    }
+    return run_conv(a, stream);
+  }
+  if (!(split && wide_packed(l) && xs && a.x_dtype == SD_DT_F32 && (a.y_dtype == SD_DT_F32 || a.y_dtype == SD_DT_SPLIT16) && !(a.tee && a.tee_add) &&
         !(a.colstat && a.T < 128))) {
     if (a.y_dtype == SD_DT_SPLIT16) return sd_set_error(SD_ERR_UNSUPPORTED, "sd_ecapa_forward: a split output needs the split wide kernel");
     return run_conv(a, stream);
   }
-  const int cp = (l.cin + 31) / 32 * 32;
-  if (a.y_dtype != SD_DT_SPLIT16 && wide_goes_narrow(l, a.M) && !a.colstat && l.cin % 4 == 0 && a.lda % 4 == 0 && a.a_col0 % 4 == 0) {
+  if (a.y_dtype != SD_DT_SPLIT16 && wide_goes_narrow(l, a.M, narrow_tiles) && !a.colstat && l.cin % 4 == 0 && a.lda % 4 == 0 && a.a_col0 % 4 == 0) {
     a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = cp;           // f32 x stays: split while staged; the folded 2^s
     a.bias = l.bias_split; a.scale = l.scale_split; a.w_scale_inv = 0.f;    // form of bias / scale serves this kernel too
     return sd_conv1d_cl_split16(&a, stream);
@@ -207,6 +225,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   // 86 % of the flops, stay on the exact-f32 kernel
   const bool split = w->split16 != 0 && dt == SD_DT_F32;
   const bool wsplit = w->split16 == 1 && dt == SD_DT_F32;
+  const long nt = sd_f16_narrow_tiles().load(std::memory_order_relaxed);      // one snapshot per forward
 
   static const bool colstat_ok = [] {     // SD_COLSTAT=0: A/B switch for measurements
     const char* e = sd_experiment_env("SD_COLSTAT");
@@ -227,10 +246,10 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     sd_conv_args a = conv_of(w->block0, x, xdt, w->n_mels, 0, b.x0, dt, C, 0, M, T, SD_ACT_RELU);
     // f32-split16x3, wide layers split: both readers of the stem's output (block 1's tdnn1 and its shortcut) take SD_DT_SPLIT16, so the
     // stem writes that form and nothing else (no f32 tensor, no pack pass) -- unless a small launch sends tdnn1 to the narrow kernel
-    x0_split = wsplit && b.x0s && b.xcs && w->block0.w_split && w->blocks[0].tdnn1.w_split && !wide_goes_narrow(w->block0, M) &&
-               !wide_goes_narrow(w->blocks[0].tdnn1, M);
+    x0_split = wsplit && b.x0s && b.xcs && wide_packed(w->block0) && wide_packed(w->blocks[0].tdnn1) && !wide_goes_narrow(w->block0, M, nt) &&
+               !wide_goes_narrow(w->blocks[0].tdnn1, M, nt);
     if (x0_split) { a.y = b.x0s; a.y_dtype = SD_DT_SPLIT16; }
-    SD_TRY(run_wide(w->block0, a, wsplit, b.xs, stream));
+    SD_TRY(run_wide(w->block0, a, wsplit, b.xs, nt, stream));
   }
   const void* xin = b.x0; int ldin = C, colin = 0;
   // where the current block input exists as SD_DT_SPLIT16 (null: it does not), and whether its f32 form was skipped
@@ -254,7 +273,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       sd_conv_args a = conv_of(blk.tdnn1, xin, dt, ldin, colin, b.r, dt, C, 0, M, T, SD_ACT_RELU);
       if (!chain) { a.tee = b.s0; a.ldt = chunk; a.tee_lo = chunk; a.tee_hi = 2 * chunk; }
       // (blocks 2..: the input is a slice of xcat, whose split twin the previous block's SE kernel has written)
-      SD_TRY(run_wide(blk.tdnn1, a, wsplit, b.xs, stream, in_sp, in_sp_ld));
+      SD_TRY(run_wide(blk.tdnn1, a, wsplit, b.xs, nt, stream, in_sp, in_sp_ld));
     }
     if (chain) {
       SD_TRY(sd_res2net_chain_f16(b.r, C, B, T, blk.res2, w->res2_scale - 1, b.wpk, b.wpk_bytes, stream));
@@ -262,8 +281,8 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       // f32-split16x3 with the wide layers split too: tdnn2 reads r as SD_DT_SPLIT16, so the narrow convs write their chunk in that
       // form directly (same bytes as the f32 chunk, no pack pass: 8 of the pass's 8 bytes per value go) and only chunk 0, which
       // tdnn1's output passes through unchanged, is packed; r itself keeps tdnn1's output (the tee_add source of every conv)
-      r_split = wsplit && b.rs && blk.tdnn2.w_split && !wide_goes_narrow(blk.tdnn2, M);
-      for (int j = 1; j < w->res2_scale && r_split; ++j) r_split = blk.res2[j - 1].w_split != nullptr;
+      r_split = wsplit && b.rs && wide_packed(blk.tdnn2) && !wide_goes_narrow(blk.tdnn2, M, nt);
+      for (int j = 1; j < w->res2_scale && r_split; ++j) r_split = blk.res2[j - 1].w_split != nullptr && !blk.res2[j - 1].bias_split;
       if (r_split) SD_TRY(sd_split16_pack_f32(static_cast<const float*>(b.r), C, 0, M, chunk, 1.f, b.rs, C, stream));
       for (int j = 1; j < w->res2_scale; ++j) {
         void* src = (j & 1) ? b.s0 : b.s1;
@@ -281,10 +300,10 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // geometry allows (the Res2Net scratch s0 is dead and holds them), else from a pass over t2
     {
       sd_conv_args a = conv_of(blk.tdnn2, b.r, dt, C, 0, b.t2, dt, C, 0, M, T, SD_ACT_RELU);
-      const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && C % 256 == 0 && !(wsplit && blk.tdnn2.w_split && wide_goes_narrow(blk.tdnn2, M)) &&
+      const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && C % 256 == 0 && !(wsplit && blk.tdnn2.w_split && wide_goes_narrow(blk.tdnn2, M, nt)) &&
                         sd_colstat_floats(M, C) * sizeof(float) <= (size_t)M * chunk * es;
       if (stat) a.colstat = static_cast<float*>(b.s0);
-      SD_TRY(run_wide(blk.tdnn2, a, wsplit, b.xs, stream, r_split ? b.rs : nullptr, C));
+      SD_TRY(run_wide(blk.tdnn2, a, wsplit, b.xs, nt, stream, r_split ? b.rs : nullptr, C));
       if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
       else SD_TRY(sd_seg_mean_std_dt(b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
     }
@@ -301,9 +320,9 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
       // block's tdnn1, the MFA conv, and the next block's shortcut below), so the f32 slice is not written and the shortcut is read
       // from the copy the previous block wrote -- unless a small launch routes the next tdnn1 to the narrow kernel, which stages f32
       const bool twin = wsplit && b.xcs != nullptr;
-      const bool next_reads_f32 = i + 1 < w->n_blocks && wide_goes_narrow(w->blocks[i + 1].tdnn1, M);
-      const bool skip_f32 = twin && w->mfa.w_split && !wide_goes_narrow(w->mfa, M) && !next_reads_f32 &&
-                            (i + 1 >= w->n_blocks || w->blocks[i + 1].tdnn1.w_split);
+      const bool next_reads_f32 = i + 1 < w->n_blocks && wide_goes_narrow(w->blocks[i + 1].tdnn1, M, nt);
+      const bool skip_f32 = twin && wide_packed(w->mfa) && !wide_goes_narrow(w->mfa, M, nt) && !next_reads_f32 &&
+                            (i + 1 >= w->n_blocks || wide_packed(w->blocks[i + 1].tdnn1));
       const bool res_twin = twin && in_sp != nullptr && res_is_twin;
       SD_TRY(sd_se_scale_residual_split(b.t2, C, b.gate, xin, ldin, colin, b.xcat, Cm, i * C, B, T, C, dt,
                                         twin ? b.xcs : nullptr, Cm, i * C, stream,
@@ -317,10 +336,10 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   // epilogue (column sums in r, dead since the last block's tdnn2)
   {
     sd_conv_args a = conv_of(w->mfa, b.xcat, dt, Cm, 0, b.h, dt, Cm, 0, M, T, SD_ACT_RELU);
-    const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && Cm % 256 == 0 && !(wsplit && w->mfa.w_split && wide_goes_narrow(w->mfa, M)) &&
+    const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && Cm % 256 == 0 && !(wsplit && w->mfa.w_split && wide_goes_narrow(w->mfa, M, nt)) &&
                       sd_colstat_floats(M, Cm) * sizeof(float) <= (size_t)M * C * es;
     if (stat) a.colstat = static_cast<float*>(b.r);
-    SD_TRY(run_wide(w->mfa, a, wsplit, b.xs, stream, b.xcs, Cm));
+    SD_TRY(run_wide(w->mfa, a, wsplit, b.xs, nt, stream, b.xcs, Cm));
     if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
     else SD_TRY(sd_seg_mean_std_dt(b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
   }
@@ -342,7 +361,9 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
                        sd_asp_attend_pool_supported(dt, T, Cm, w->att_channels);
     if (fused) {
       // (split16 mode: the same f32 tensors, the logits product on the f16 matrix cores with split operands)
-      SD_TRY(sd_asp_attend_pool_dt(b.a1, w->asp_conv.w, b.h, split ? SD_DT_SPLIT16 : dt, Cm, B, T, Cm, w->att_channels, w->asp_eps, b.pooled, stream));
+      // (the weights' 2^s: asp_conv.split_scale_inv = 2^-s from the host, data dependent like every other split weight's)
+      const float ws = w->asp_conv.split_scale_inv > 0.f ? 1.f / w->asp_conv.split_scale_inv : 256.f;
+      SD_TRY(sd_asp_attend_pool_scaled(b.a1, w->asp_conv.w, b.h, split ? SD_DT_SPLIT16 : dt, Cm, B, T, Cm, w->att_channels, w->asp_eps, ws, b.pooled, stream));
     } else {
       sd_conv_args c = conv_of(w->asp_conv, b.a1, dt, w->att_channels, 0, b.e, dt, Cm, 0, M, T, SD_ACT_NONE);
       SD_TRY(run_conv(c, stream));

@@ -148,7 +148,7 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
           h8s hi, lo;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float w = __builtin_amdgcn_fmed3f(v[i][e], -65504.f, 65504.f);
+            const float w = sd_split16_clamp(v[i][e]);
             hi[e] = (_Float16)w;
             lo[e] = (_Float16)(w - (float)hi[e]);
           }

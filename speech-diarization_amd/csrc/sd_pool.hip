@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void se_scale_residual_kernel(const T* x, int 
           h4v hi, lo;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float w = __builtin_amdgcn_fmed3f((float)o[e], -65504.f, 65504.f);
+            const float w = sd_split16_clamp((float)o[e]);
             hi[e] = (_Float16)w;
             lo[e] = (_Float16)(w - (float)hi[e]);
           }
@@ -376,7 +376,6 @@ __global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __rest
   if (want_std) out[(size_t)b * 2 * C + C + c] = sqrtf(fmaxf(q * inv - m1 * m1, eps));
 }
 
-// x (f32, already L2-normalised, row stride ldx) -> two f16 operand matrices [N][3 Dk] for the
 }  // namespace
 
 // f32 -> f16 (round to nearest even), n % 8 == 0 elements, both 16-byte aligned: the features in front of the f16 stem

@@ -48,14 +48,22 @@ def pack_conv_weight(w: np.ndarray, dtype=np.float32) -> np.ndarray:
     return out
 
 
+def split16_exponent(w: np.ndarray) -> int:
+    """s with max |w| 2^s in [512, 1024) (0 for an all-zero tensor)."""
+    wmax = float(np.abs(w).max())
+    if not wmax > 0:
+        return 0
+    s = int(np.floor(np.log2(1024.0 / wmax)))
+    return s - 1 if wmax * 2.0 ** s >= 1024.0 else s
+
+
 def pack_conv_weight_split16(w: np.ndarray):
     """[cout, cin, k] f32 -> (SD_DT_SPLIT16 [cout, k, cin_pad / 32, 64] f16, s): the weights scaled by 2^s (max |w| 2^s in
     [512, 1024): the low halves of small weights stay clear of the f16 subnormals, nothing overflows), every value split
     hi = f16(v), lo = f16(v - hi), interleaved per 32 input channels [hi x 32 | lo x 32] (sd_hip.h: SD_DT_SPLIT16)."""
     cout, cin, k = w.shape
     cp = _pad_to(cin, 32)
-    wmax = float(np.abs(w).max())
-    s = int(np.floor(np.log2(1024.0 / wmax))) - (1 if wmax * 2.0 ** np.floor(np.log2(1024.0 / wmax)) >= 1024.0 else 0) if wmax > 0 else 0
+    s = split16_exponent(w)
     v = np.zeros((cout, k, cp), dtype=np.float32)
     v[:, :, :cin] = np.transpose(w, (0, 2, 1)) * np.float32(2.0 ** s)          # exact: power of two
     hi = v.astype(np.float16)
@@ -122,6 +130,8 @@ class EcapaWeights:
         self._fill(W.asp_tdnn_h, wa[:, :cm], None, bn_affine(sd, "asp.tdnn.norm.norm"), 1)
         self._fill(W.asp_tdnn_g, wa[:, cm:], _np(sd["asp.tdnn.conv.conv.bias"]), None, 1, per_segment=True)
         self._fill(W.asp_conv, _np(sd["asp.conv.conv.weight"]), _np(sd["asp.conv.conv.bias"]), None, 1)
+        if precision in ("f32s", "f32ns"):      # the fused pooling kernel splits these f32 weights in registers: it needs their 2^s
+            W.asp_conv.split_scale_inv = float(2.0 ** -split16_exponent(_np(sd["asp.conv.conv.weight"])))
         # asp_bn is an affine map in front of a linear layer: fold it into fc (float64 on the host)
         s, t = bn_affine(sd, "asp_bn.norm")
         wf = _np(sd["fc.conv.weight"]).astype(np.float64)[:, :, 0]

@@ -20,10 +20,12 @@ from .engine import EmbeddingEngine
 
 class StreamingEmbedder:
     """The last `window_s` of every channel live in ONE device buffer that is written in place: a doubled ring
-    ([channels, 2 * win]; a hop is stored at q and at q + win, so the newest window is always the contiguous span
-    starting at (q + hop) mod win).  The fbank kernel reads the windows where they lie (`sd_fbank_windows_f32` with a
-    per-channel start offset held in a small device array), so a hop costs two hop-sized copies and no allocation;
-    the captured graph replays against the same buffer and start array (its launches hold their addresses)."""
+    ([channels, 2 * win]; sample i of the ring is stored at i and at i + win, so the newest window is always the
+    contiguous span starting at the write position q mod win).  The fbank kernel reads the windows where they lie
+    (`sd_fbank_windows_f32` with a per-channel start offset held in a small device array), so a hop costs two
+    hop-sized copies (four when the hop wraps around the end of the ring, i.e. when the window is not a whole number
+    of hops) and no allocation; the captured graph replays against the same buffer and start array (its launches hold
+    their addresses).  Any 0 < hop <= window is accepted."""
 
     def __init__(self, engine: EmbeddingEngine, channels: int = 16, window_s: float = 2.0, hop_s: float = 0.25, sr: int = 16000,
                  use_graph: bool = True):
@@ -31,17 +33,15 @@ class StreamingEmbedder:
         self.channels, self.sr = channels, sr
         self.win = int(round(window_s * sr))
         self.hop = int(round(hop_s * sr))
-        if self.win % self.hop:
-            raise ValueError(f"window ({self.win} samples) must be a whole number of hops ({self.hop})")
+        if not 0 < self.hop <= self.win:
+            raise ValueError(f"hop ({self.hop} samples) must be positive and at most the window ({self.win})")
         dev = engine.device
         self._cap = 2 * self.win
         self._buf = torch.zeros((channels, self._cap), dtype=torch.float32, device=dev)
-        self._phases = self.win // self.hop
-        base = torch.arange(channels, dtype=torch.int64) * self._cap
-        # window start of every channel in the flat buffer, for each of the win / hop ring phases
-        self._start_table = torch.stack([base + ((ph + 1) * self.hop) % self.win for ph in range(self._phases)]).to(dev)
-        self._starts = self._start_table[self._phases - 1].clone()      # static address (captured by the graph)
-        self._phase = 0
+        # window start of channel c in the flat buffer = c * cap + (write position mod win)
+        self._base = (torch.arange(channels, dtype=torch.int64) * self._cap).to(dev)
+        self._starts = self._base.clone()               # static address (captured by the graph)
+        self._q = 0                                     # write position in the ring, 0 <= q < win
         self._static_out = None
         self._graph = None
         self.use_graph = use_graph
@@ -76,11 +76,14 @@ class StreamingEmbedder:
         if chunk.shape != (self.channels, self.hop):
             raise ValueError(f"expected a [{self.channels}, {self.hop}] hop, got {tuple(chunk.shape)}")
         chunk = chunk.to(self._buf.device, dtype=torch.float32, non_blocking=True)
-        q = self._phase * self.hop
-        self._buf[:, q:q + self.hop].copy_(chunk)                        # in place, both images of the ring
-        self._buf[:, q + self.win:q + self.win + self.hop].copy_(chunk)
-        self._starts.copy_(self._start_table[self._phase])
-        self._phase = (self._phase + 1) % self._phases
+        q, win = self._q, self.win
+        first = min(self.hop, win - q)                                   # the piece up to the end of the ring ...
+        for lo, n, src in ((q, first, chunk[:, :first]), (0, self.hop - first, chunk[:, first:])):   # ... and the wrapped rest
+            if n > 0:
+                self._buf[:, lo:lo + n].copy_(src)                       # in place, both images of the ring
+                self._buf[:, lo + win:lo + win + n].copy_(src)
+        self._q = (q + self.hop) % win
+        torch.add(self._base, self._q, out=self._starts)                 # in place: the captured launches read this array
         if self._graph is None:
             return self._embed()
         self._graph.replay()

@@ -338,3 +338,99 @@ def test_fused_attention_pooling_split16_matches_f64(dev, B, T, Cc):
     if T > 1:
         assert (got[:, Cc:] - sd).abs().max() < 2e-5
     assert (got[:, :Cc] - mu).abs().max() < 4.0 * (f32[:, :Cc] - mu).abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("width,att,B,n", [(64, 32, 3, 16000), (128, 32, 2, 9600), (256, 32, 4, 32000), (256, 128, 41, 32000), (512, 128, 3, 32000)])
+def test_ecapa_split16_small_geometries_match_oracle(dev, width, att, B, n):
+    """with C <= 256 the wide-ROLE layers (stem, tdnn1, tdnn2) carry the NARROW split packing (weights scaled by 2^s, no
+    folded bias / BatchNorm scale); the schedule must run them on the 128x128 split kernel with `w_scale_inv` (or exact f32), never on
+    the folded-scale form.  256 < C < 1024 carries no split packing on the wide layers at all.  41 segments = 8241 rows: past the
+    small-launch routing, column statistics on.  The exact-f32 bars against the float64 oracle, for "f32s" and "f32ns"."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    cfg = synth.EcapaConfig(channels=(width, width, width, width, 3 * width), attention_channels=att, lin_neurons=192, res2net_scale=8, se_channels=32)
+    sd = synth.make_ecapa_state_dict(1234, cfg)
+    wav = synth.synthetic_segments(5, B, n)
+    wd = torch.from_numpy(wav).to(dev)
+    ref = pipeline_ref.encode_batch_ref(sd, wav[:6], torch.float64)
+    for precision in ("f32s", "f32ns", "f32"):
+        got = EmbeddingEngine(sd, dev, precision=precision).embed(wd).cpu().numpy()[:6]
+        cd = _cos_dist(got, ref)
+        assert cd.max() < 1e-5, (precision, cd)
+        assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max(), precision
+
+
+def test_split_sites_keep_nan(dev):
+    """every f32 -> (hi, lo) split site clamps to the f16 range AND keeps NaN (`sd_split16_clamp`): the pack kernel, the
+    narrow kernel's staging, its SD_DT_SPLIT16 output and the wide kernel's.  A NaN activation row gives a NaN output row (it used to
+    become -65504) and leaves the other rows' bits alone; +-inf and out-of-range values clamp to +-65504."""
+    from speech_diarization_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, cin, cout = 2, 150, 128, 128
+    x = torch.randn(B * T, cin, generator=g).to(dev)
+    w = torch.randn(cout, cin, 3, generator=g) / np.sqrt(3 * cin)
+    ws, s = ops.pack_weight_split16(w, dev)
+    clean = ops.conv1d_cl_split16(x, ws, s, T, cin=cin, dil=2, act="relu", narrow=True)
+    xn = x.clone()
+    xn[200, 5] = float("nan")                          # row 200 = frame 50 of segment 1; taps reach frames 48, 50, 52
+    hit = [T + 48, T + 50, T + 52]
+    y = ops.conv1d_cl_split16(xn, ws, s, T, cin=cin, dil=2, act="relu", narrow=True)
+    assert bool(torch.isnan(y[hit]).all())
+    keep = torch.ones(B * T, dtype=torch.bool, device=dev)
+    keep[hit] = False
+    assert torch.equal(y[keep], clean[keep])
+    ysp = torch.zeros((B * T, 2 * cout), device=dev, dtype=torch.float16)
+    ops.conv1d_cl_split16(xn, ws, s, T, cin=cin, dil=2, act="relu", narrow=True, out=torch.zeros_like(y), out_split=ysp)
+    assert torch.equal(ysp.view(torch.int16), ops.split16_pack(y, 0, cout).view(torch.int16))       # NaN rows included, bit for bit
+    assert bool(torch.isnan(ysp[hit].float()).all())
+    # the pack pass: NaN stays NaN, +-inf / out-of-range clamp
+    v = torch.tensor([[float("nan"), float("inf"), -float("inf"), 1e6, -1e6, 1.5, 0.0, -2.25] * 4], device=dev)
+    p = ops.split16_pack(v).float()
+    hi, lo = p[0, :8], p[0, 32:40]
+    assert bool(torch.isnan(hi[0])) and bool(torch.isnan(lo[0]))
+    assert hi[1:].tolist() == [65504.0, -65504.0, 65504.0, -65504.0, 1.5, 0.0, -2.25] and lo[1:].abs().max() == 0
+    # wide kernel (256x256), split output from the LDS-staged epilogue
+    cinw, coutw = 256, 512
+    xw = torch.randn(B * T, cinw, generator=g).to(dev)
+    xw[77, 3] = float("nan")
+    ww = torch.randn(coutw, cinw, 1, generator=g) / np.sqrt(cinw)
+    wws, sw = ops.pack_weight_split16(ww, dev)
+    bias, scale, shift = torch.randn(coutw, generator=g).to(dev), (torch.rand(coutw, generator=g) + 0.5).to(dev), torch.randn(coutw, generator=g).to(dev)
+    kw = dict(cin=cinw, bias=bias, act="relu", scale=scale, shift=shift)
+    y32 = ops.conv1d_cl_split16(xw, wws, sw, T, **kw)
+    assert bool(torch.isnan(y32[77]).all()) and int(torch.isnan(y32).any(dim=1).sum()) == 1
+    yws = torch.zeros((B * T, 2 * coutw), device=dev, dtype=torch.float16)
+    ops.conv1d_cl_split16(xw, wws, sw, T, out=torch.zeros_like(y32), out_split=yws, **kw)
+    assert torch.equal(yws.view(torch.int16), ops.split16_pack(y32, 0, coutw).view(torch.int16))
+
+
+def test_split16_attention_logits_with_large_weights(dev):
+    """the fused pooling kernel's SPLIT logits product scaled its f32 weights by a fixed 2^8 before the f16 cast: |w| >= 256
+    overflowed to inf and the logits to NaN.  The forward now passes the layer's own 2^s (max |w| 2^s in [512, 1024), from the host,
+    as for every other split weight); the stand-alone entry keeps 2^8 and clamps.  An ECAPA whose attention conv has |w| up to ~600:
+    f32s and f32ns against the float64 oracle at the exact-f32 bars."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import ops, synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    cfg = synth.EcapaConfig(channels=(256, 256, 256, 256, 768), attention_channels=128, lin_neurons=192, res2net_scale=8, se_channels=32)
+    sd = dict(synth.make_ecapa_state_dict(1234, cfg))
+    w = np.array(sd["asp.conv.conv.weight"], dtype=np.float32)
+    # large, but few: one strong tap per output channel keeps the softmax from collapsing onto a single frame everywhere
+    big = np.zeros_like(w)
+    big[np.arange(w.shape[0]), np.arange(w.shape[0]) % w.shape[1], 0] = 600.0 * np.sign(w[np.arange(w.shape[0]), np.arange(w.shape[0]) % w.shape[1], 0])
+    sd["asp.conv.conv.weight"] = (w + big).astype(np.float32)
+    wav = synth.synthetic_segments(7, 3, 32000)
+    ref = pipeline_ref.encode_batch_ref(sd, wav, torch.float64)
+    for precision in ("f32", "f32s", "f32ns"):
+        got = EmbeddingEngine(sd, dev, precision=precision).embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+        assert np.isfinite(got).all(), precision
+        assert _cos_dist(got, ref).max() < 1e-5, (precision, _cos_dist(got, ref))
+    # the stand-alone entry (fixed 2^8): finite for any weight, exact while |w| 2^8 stays inside the f16 range
+    g = torch.Generator().manual_seed(3)
+    B, T, Cc = 2, 101, 256
+    a1 = torch.tanh(torch.randn(B * T, 128, generator=g)).to(dev)
+    h = (torch.randn(B * T, Cc, generator=g) * 1.5).to(dev)
+    wc = torch.randn(Cc, 128, 1, generator=g) * 100.0
+    out = ops.asp_attend_pool(a1, ops.pack_weight(wc, dev), h, B, T, split16=True)
+    assert bool(torch.isfinite(out).all())

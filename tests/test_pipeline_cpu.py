@@ -83,7 +83,7 @@ def test_der_scorer():
 
 def test_streaming_ring_is_written_in_place_and_reads_the_last_window():
     """configs[3] host logic without a GPU: the doubled ring of `StreamingEmbedder` (two hop-sized in-place copies per
-    hop, window start offsets from a table) hands `embed_windows` exactly the last `window_s` of every channel."""
+    hop, window start offset = write position) hands `embed_windows` exactly the last `window_s` of every channel."""
     import torch
     from speech_diarization_amd.streaming import StreamingEmbedder
 
@@ -113,8 +113,18 @@ def test_streaming_ring_is_written_in_place_and_reads_the_last_window():
     assert st._buf.data_ptr() == buf_ptr                       # never re-allocated
     with pytest.raises(ValueError):
         st.push(torch.zeros(3, 7))
-    with pytest.raises(ValueError):
-        StreamingEmbedder(eng, channels=1, window_s=0.5, hop_s=0.3, sr=1600, use_graph=False)
+    # a window that is NOT a whole number of hops: the hop wraps around the end of the ring
+    st = StreamingEmbedder(eng, channels=2, window_s=0.5, hop_s=0.3, sr=1000, use_graph=False)     # win 500, hop 300
+    feed = rng.standard_normal((2, 300 * 9)).astype(np.float32)
+    for h in range(9):
+        st.push(torch.from_numpy(feed[:, h * 300:(h + 1) * 300]))
+        want = np.zeros((2, 500), np.float32)
+        have = feed[:, max(0, (h + 1) * 300 - 500):(h + 1) * 300]
+        want[:, 500 - have.shape[1]:] = have
+        assert np.array_equal(eng.seen[-1].numpy(), want) and np.array_equal(st.ring.numpy(), want), h
+    for bad in (0.0, 0.6):
+        with pytest.raises(ValueError):
+            StreamingEmbedder(eng, channels=1, window_s=0.5, hop_s=bad, sr=1600, use_graph=False)
 
 
 def test_windows_read_in_place_are_the_rows_the_host_path_gathers(monkeypatch, tmp_path):

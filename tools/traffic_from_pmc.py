@@ -23,7 +23,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"([A-Za-z_0-9]+_kernel)\b", r["Kernel_Name"]) or re.search(r"\d([a-z][a-z0-9_]*?_kernel)", r["Kernel_Name"])   # demangled, else Itanium-mangled
+        m = re.search(r"([A-Za-z_0-9]+_kernel(?:<(?:true|false)>)?)", r["Kernel_Name"]) or re.search(r"\d([a-z][a-z0-9_]*?_kernel)", r["Kernel_Name"])   # demangled, else Itanium-mangled
         if not m:
             continue                        # torch / runtime helper kernels
         name = m.group(1)
