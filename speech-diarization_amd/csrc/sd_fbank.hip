@@ -34,12 +34,14 @@
 //   * LDS sample image: sample i of a span sits at word i + 4 (i / 160): frame starts (stride 164 words) and every
 //     aligned group of 4 samples stay 16-byte aligned, and the 16 frames of a ds_read_b128 lane group fall on 16
 //     distinct bank slots (41 j mod 16 = 9 j).
-// Measured (MI355X, 5000 segments of 2 s): 1.40 ms main kernel + 0.21 ms finalize (round 1: 3.0 + 0.21), 687 GB/s of the
-// 192 320 algorithmic bytes per segment.  Two things found on the way (both hipcc codegen, both worth ~1 ms):
+// Measured (MI355X, rocprofv3, 10 000 segments of 2 s per launch): 2.32 ms main kernel + 0.45 ms finalize (round 1: 6.0 + 0.42),
+// 830 GB/s of the 192 320 algorithmic bytes per segment for the main kernel alone, 695 GB/s with the finalize pass.  Since round 4
+// utterances of up to 216 frames take the one-launch kernel of sd_fbank_utt.hip (2.10 ms for the same work); this kernel serves
+// the longer ones.  Two things found on the way (both hipcc codegen, both worth ~1 ms per 5000 segments):
 // a multiply placed next to the staging loads made every load wait on its own (79 `s_waitcnt vmcnt(0)`), and predicated
 // loads become branches with a wait each; the staging loop therefore loads unconditionally from a clamped index and
 // selects the zero padding afterwards.
-#include "sd_common.h"
+#include "sd_fbank_internal.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -433,13 +435,6 @@ __global__ void fbank_finalize_kernel(float* out, int ld_out, int T, int n_mels,
 
 }  // namespace
 
-struct sd_fbank_plan {
-  int n_fft, hop, n_mels, pad_mode, log_mode;
-  float log_eps, top_db;
-  void* basis16_dev;       // split-f16 kernel: f16 [pass][k step][tile][Chi | Clo | Shi | Slo][64][8]
-  void* melw16_dev;        // bf16 [bin tile][k half][mel tile][W1 | W2][64][8]
-};
-
 namespace {
 // round-to-nearest-even f32 -> bf16 bits (finite inputs)
 unsigned short bf16_bits(float v) {
@@ -514,7 +509,7 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
                 m16[o] = part == 0 ? w1 : bf16_bits(w - bf16_value(w1));
               }
   }
-  sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr};
+  sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipError_t e1 = hipMalloc(&plan->basis16_dev, V2_BASIS_BYTES);
   hipError_t e2 = e1 == hipSuccess ? hipMalloc(&plan->melw16_dev, V2_MELW_BYTES) : e1;
   if (e1 == hipSuccess && e2 == hipSuccess) {
@@ -529,6 +524,12 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
     delete plan;
     return nullptr;
   }
+  if (sd_fbank_utt_create_tables(plan, window, mel_fb) != SD_OK) {      // tables of the one-launch kernel (sd_fbank_utt.hip)
+    (void)hipFree(plan->basis16_dev);
+    (void)hipFree(plan->melw16_dev);
+    delete plan;
+    return nullptr;
+  }
   return plan;
 }
 
@@ -536,6 +537,7 @@ extern "C" void sd_fbank_plan_destroy(sd_fbank_plan* plan) {
   if (!plan) return;
   (void)hipFree(plan->basis16_dev);
   (void)hipFree(plan->melw16_dev);
+  sd_fbank_utt_destroy_tables(plan);
   delete plan;
 }
 
@@ -580,6 +582,9 @@ static int fbank_launch(const sd_fbank_plan* plan, const float* wav_dev, long lo
     SD_CHECK_ARG(n >= 1, "sd_fbank_f32: empty waveform");
   SD_CHECK_ARG(ws_dev != nullptr && ws_bytes >= sd_fbank_workspace_bytes(plan, B, n),
                "sd_fbank_f32: workspace too small (%zu < %zu)", ws_bytes, sd_fbank_workspace_bytes(plan, B, n));
+  // utterances whose padded signal fits the CU's LDS: ONE launch, one workgroup per utterance (sd_fbank_utt.hip)
+  if (n_total >= 4 && sd_fbank_utt_supported(plan, n))      // (its 16-byte loads need four samples behind `wav`)
+    return sd_fbank_utt_launch(plan, wav_dev, n_total, starts_dev, B, n, mean_norm, out_dev, ld_out, stream);
   const int T = 1 + n / HOP;
   Fbank2Args a;
   a.wav = wav_dev; a.B = B; a.n = n; a.T = T;

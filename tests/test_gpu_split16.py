@@ -363,27 +363,30 @@ def test_ecapa_split16_small_geometries_match_oracle(dev, width, att, B, n):
 
 def test_split_sites_keep_nan(dev):
     """every f32 -> (hi, lo) split site clamps to the f16 range AND keeps NaN (`sd_split16_clamp`): the pack kernel, the
-    narrow kernel's staging, its SD_DT_SPLIT16 output and the wide kernel's.  A NaN activation row gives a NaN output row (it used to
-    become -65504) and leaves the other rows' bits alone; +-inf and out-of-range values clamp to +-65504."""
+    narrow kernel's staging, its SD_DT_SPLIT16 output and the wide kernel's.  A NaN activation reaches the matrix cores as a NaN (it used
+    to become -65504, a finite value) and leaves the other rows' bits alone; +-inf and out-of-range values clamp to +-65504.  What the f16
+    MFMA makes of a NaN operand on gfx950 is -inf, not NaN (tools/probe_nan.py: the plain f16 conv kernel does the same, the exact-f32
+    kernel returns NaN): the affected rows come out non-finite, which is what a caller can test for.  (No activation here: the epilogue's
+    ReLU is `fmaxf(v, 0)`, which maps NaN and -inf to 0 in every precision mode.)"""
     from speech_diarization_amd import ops
     g = torch.Generator().manual_seed(5)
     B, T, cin, cout = 2, 150, 128, 128
     x = torch.randn(B * T, cin, generator=g).to(dev)
     w = torch.randn(cout, cin, 3, generator=g) / np.sqrt(3 * cin)
     ws, s = ops.pack_weight_split16(w, dev)
-    clean = ops.conv1d_cl_split16(x, ws, s, T, cin=cin, dil=2, act="relu", narrow=True)
+    clean = ops.conv1d_cl_split16(x, ws, s, T, cin=cin, dil=2, act=None, narrow=True)
     xn = x.clone()
     xn[200, 5] = float("nan")                          # row 200 = frame 50 of segment 1; taps reach frames 48, 50, 52
     hit = [T + 48, T + 50, T + 52]
-    y = ops.conv1d_cl_split16(xn, ws, s, T, cin=cin, dil=2, act="relu", narrow=True)
-    assert bool(torch.isnan(y[hit]).all())
+    y = ops.conv1d_cl_split16(xn, ws, s, T, cin=cin, dil=2, act=None, narrow=True)
+    assert not bool(torch.isfinite(y[hit]).any())
     keep = torch.ones(B * T, dtype=torch.bool, device=dev)
     keep[hit] = False
     assert torch.equal(y[keep], clean[keep])
     ysp = torch.zeros((B * T, 2 * cout), device=dev, dtype=torch.float16)
-    ops.conv1d_cl_split16(xn, ws, s, T, cin=cin, dil=2, act="relu", narrow=True, out=torch.zeros_like(y), out_split=ysp)
+    ops.conv1d_cl_split16(xn, ws, s, T, cin=cin, dil=2, act=None, narrow=True, out=torch.zeros_like(y), out_split=ysp)
     assert torch.equal(ysp.view(torch.int16), ops.split16_pack(y, 0, cout).view(torch.int16))       # NaN rows included, bit for bit
-    assert bool(torch.isnan(ysp[hit].float()).all())
+    assert bool((ysp[hit].float().abs() == 65504.0).any(dim=1).all())                               # (-inf clamps on its way into the split)
     # the pack pass: NaN stays NaN, +-inf / out-of-range clamp
     v = torch.tensor([[float("nan"), float("inf"), -float("inf"), 1e6, -1e6, 1.5, 0.0, -2.25] * 4], device=dev)
     p = ops.split16_pack(v).float()
@@ -397,9 +400,9 @@ def test_split_sites_keep_nan(dev):
     ww = torch.randn(coutw, cinw, 1, generator=g) / np.sqrt(cinw)
     wws, sw = ops.pack_weight_split16(ww, dev)
     bias, scale, shift = torch.randn(coutw, generator=g).to(dev), (torch.rand(coutw, generator=g) + 0.5).to(dev), torch.randn(coutw, generator=g).to(dev)
-    kw = dict(cin=cinw, bias=bias, act="relu", scale=scale, shift=shift)
+    kw = dict(cin=cinw, bias=bias, act=None, scale=scale, shift=shift)
     y32 = ops.conv1d_cl_split16(xw, wws, sw, T, **kw)
-    assert bool(torch.isnan(y32[77]).all()) and int(torch.isnan(y32).any(dim=1).sum()) == 1
+    assert not bool(torch.isfinite(y32[77]).any()) and int((~torch.isfinite(y32)).any(dim=1).sum()) == 1
     yws = torch.zeros((B * T, 2 * coutw), device=dev, dtype=torch.float16)
     ops.conv1d_cl_split16(xw, wws, sw, T, out=torch.zeros_like(y32), out_split=yws, **kw)
     assert torch.equal(yws.view(torch.int16), ops.split16_pack(y32, 0, coutw).view(torch.int16))
