@@ -14,7 +14,7 @@ block on-device.  Weak scaling: every rank owns `--segments` segments.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the implicit-GEMM
 conv of the wide layers on the f32 matrix cores); `roofline_other_convs` the remaining conv launches;
-`roofline_fbank` is the HBM-bound fbank kernel.  Kernel
+`roofline_fbank` is the fbank kernel, priced against HBM (its algorithmic bytes).  Kernel
 durations are measured live with HIP events on the launch stream (sd_profile_*).
 `cpu_baseline` times the CPU oracle (torch f32) on this host's cores on a bounded sample.
 """
@@ -401,9 +401,9 @@ def main():
                 "traffic": traffic.get(other_kernel), "traffic_source": "file profiles/traffic.json; NOT measured in this run",
             },
             "roofline_fbank": {
-                "kernel": "fbank_logmel_kernel", "bound": "hbm",
+                "kernel": "fbank_utt_kernel (ONE launch per batch: waveform -> log-mel incl. the utterance-level top_db floor and mean removal)", "bound": "hbm",
                 "achieved": fb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb_gbs / HBM_PEAK_GBS,
-                "traffic": traffic.get("fbank_logmel_kernel"),
+                "traffic": traffic.get("fbank_utt_kernel"),
                 "traffic_source": "file profiles/traffic.json; NOT measured in this run",
                 "launches": fb_n, "avg_launch_ms": fb_ms / max(fb_n, 1),
                 "bytes_per_launch": fb_bytes / max(fb_n, 1),
