@@ -55,6 +55,29 @@ def test_fbank_keeps_its_accuracy_at_every_signal_level(dev, kind, level):
     assert np.abs(got - ref).max() < tol, (level, np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("kind", ["torchaudio", "speechbrain"])
+@pytest.mark.parametrize("n", [801, 3203, 16001, 34559, 34560, 35003])
+def test_fbank_both_kernels_at_their_length_switch(dev, kind, n):
+    """Utterances of up to 216 frames (n <= 34 559) take the one-launch kernel (sd_fbank_utt.hip: one workgroup per utterance,
+    factored DFT, floor + mean in LDS), longer ones the folded-DFT kernel + finalize pass (sd_fbank.hip): both sides of the switch,
+    lengths that are not multiples of 4 (the one-launch kernel loads groups of four samples) and one that ends inside a tile, against
+    float64 with a 60 dB quieter stretch (the one-launch kernel scales by the utterance's PEAK: the quiet part must keep its accuracy)."""
+    from oracle import fbank_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import fbank_device
+    from speech_diarization_amd.features import FbankPlan
+    wav = synth.synthetic_segments(n, 3, n, std=0.2)
+    wav[1, n // 3: 2 * n // 3] *= 1e-3
+    wav[2] *= 1e-2
+    plan = FbankPlan(kind)
+    for mean_norm in (True, False):
+        got = fbank_device(torch.from_numpy(wav).to(dev), plan, mean_norm=mean_norm).cpu().numpy()
+        ref = (fbank_ref.fbank_batch_ref(wav, mean_nor=mean_norm) if kind == "torchaudio" else fbank_ref.speechbrain_fbank_ref(wav, mean_norm=mean_norm))
+        assert got.shape == ref.shape == (3, 1 + n // 160, 80)
+        tol = 2e-4 if kind == "torchaudio" else 1e-3
+        assert np.abs(got - ref).max() < tol, (n, mean_norm, np.abs(got - ref).max())
+
+
 def test_fbank_known_answers(dev):
     """all-zero waveform -> every bin log(eps) -> exactly 0 after mean-norm; pure tone -> peak at its mel bin."""
     from speech_diarization_amd.engine import fbank_device
