@@ -11,6 +11,7 @@ struct sd_fbank_plan {
   void* utt_a1_dev;        // factored kernel, stage 1: f16 [25 n2][hi | lo][64 lanes][8]
   void* utt_a2_dev;        // factored kernel, stage 2: f16 [2 row tiles][4 k steps][hi | lo][64 lanes][8]
   void* utt_melw_dev;      // factored kernel, mel: bf16 [9 problems][2 row tiles][3 mel tiles][W1 | W2][64 lanes][8]
+  void* utt16_tables_dev;  // 16-frame-tile factored kernel (sd_fbank_utt16.hip): all of its fragment tables, 1 KB each
 };
 
 // device tables of the factored kernel from the window (n_fft values) and the mel filterbank [n_fft / 2 + 1][n_mels]
@@ -20,3 +21,10 @@ void sd_fbank_utt_destroy_tables(sd_fbank_plan* plan);
 bool sd_fbank_utt_supported(const sd_fbank_plan* plan, int n);
 int sd_fbank_utt_launch(const sd_fbank_plan* plan, const float* wav_dev, long long n_total, const long long* starts_dev, int B, int n,
                         int mean_norm, float* out_dev, int ld_out, hipStream_t stream);
+
+// the same with 16-frame tiles and two waves per SIMD (sd_fbank_utt16.hip): utterances of up to 208 frames
+int sd_fbank_utt16_create_tables(sd_fbank_plan* plan, const float* window, const float* mel_fb);
+void sd_fbank_utt16_destroy_tables(sd_fbank_plan* plan);
+bool sd_fbank_utt16_supported(const sd_fbank_plan* plan, int n);
+int sd_fbank_utt16_launch(const sd_fbank_plan* plan, const float* wav_dev, long long n_total, const long long* starts_dev, int B, int n,
+                          int mean_norm, float* out_dev, int ld_out, hipStream_t stream);

@@ -664,7 +664,7 @@ extern "C" int sd_debug_read_utt_stamps(unsigned long long* host, int n) {
 #endif
 
 bool sd_fbank_utt_supported(const sd_fbank_plan* plan, int n) {
-  static const bool on = [] { const char* e = sd_experiment_env("SD_FBANK_UTT"); return !(e && e[0] == '0'); }();   // A/B switch
+  static const bool on = [] { const char* e = sd_experiment_env("SD_FBANK_UTT"); return !(e && atoi(e) == 0); }();   // A/B switch: 0 = folded kernel, 32 = this one, 16 (default) = sd_fbank_utt16.hip
   if (!on || !plan->utt_a1_dev) return false;
   const int T = 1 + n / HOP;
   return T <= UTT_MAX_T && utt_lds_bytes(n, T) <= (size_t)LDS_LIMIT;

@@ -1,0 +1,647 @@
+// Log-mel filterbank in ONE launch, 16-frame tiles: the form of sd_fbank_utt.hip that runs TWO waves per SIMD.
+//
+// sd_fbank_utt.hip (32-frame tiles on 32x32x16 MFMAs) keeps a frame's stage-1 sums on two lanes: 250 registers per lane, one
+// wave per SIMD, two passes over stage 1, and ends up bound by instruction issue (~6 cycles per instruction for a wave that
+// is alone on its SIMD, matrix pipe 23 % busy).  Here a tile is 16 frames on v_mfma_f32_16x16x32_f16: a frame's state lies on FOUR
+// lanes (lane group g = lane >> 4 holds accumulator rows 4 g .. 4 g + 3), accumulators are 4 registers instead of 16, and the
+// whole per-lane state fits 256 registers: eight waves per workgroup, two per SIMD, one pass, half the instructions per frame.
+//
+// Arithmetic (same contract and same scales as sd_fbank_utt.hip; [REF speech_encode.py:17-36, 77]):
+//   400 = 16 x 25, n = 25 n1 + n2.  Stage 1, per n2: Y[k1, n2] = sum_{n1 < 16} w[n] x[n] e^{-2 pi i k1 n / 400}.  x is real, so
+//   Y[16 - k1, n2] = e^{-2 pi i n2 / 25} conj Y[k1, n2]: k1 = 1..7 are complex, Y[0, n2] is real and Y[8, n2] e^{+i pi n2 / 25} =: rho[n2]
+//   is real: SIXTEEN real rows per n2 = one 16-row MFMA (K = 32 with the upper half of the matrix zero).  Rows by lane group:
+//   g = 0: k1 = 1, 2; g = 1: k1 = 3, 4; g = 2: k1 = 5, 6; g = 3: k1 = 7 and the two reals (Y[0], rho): a "pair" of problems per group.
+//   Stage 2, per problem: a 25-point DFT over n2.  Its contraction index n2 lives in separate registers of ONE lane group; a 4 x 4
+//   transpose between four registers (n2 = 4 m .. 4 m + 3) and the four lane groups (v_permlane16_swap + v_permlane32_swap, in
+//   place) turns that into "register = pair, lane group g = n2 mod 4", i.e. the B fragment of a K = 32 step: k = 8 g + 2 m' + part
+//   <-> n2 = 4 (4 s + m') + g.  Complex problems share one 64 x 64 matrix (outputs idx 0..12 are bins k1 + 16 idx, idx 13..24 the
+//   conjugates of bins 16 - k1 + 16 (24 - idx)); the pair of reals has its own (rows 0..12: bins 16 k2, rows 13..25: bins 8 + 16 k2
+//   with the phase e^{-i pi n2 / 25} folded in).  A lane then holds re / im of two outputs per 16-row tile: eight powers per problem
+//   = the B fragment of ONE K = 32 step of the mel product (80 mels = five 16-row tiles, split bf16 as before).
+// Per 16-frame tile: 75 + 192 + 120 MFMAs of 16 cycles (sd_fbank_utt.hip per 16 frames: 264 of 32).
+#include "sd_fbank_internal.h"
+#include <cmath>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+constexpr int NFFT = 400;
+constexpr int HOP = 160;
+constexpr int NFREQ = 201;
+constexpr int NN2 = 25;
+constexpr int NBLK = 7;                 // blocks of four n2 (28 >= 25)
+constexpr int FT = 16;                  // frames per wave tile
+constexpr int MELP = 81;
+constexpr int U16_MAX_T = 208;          // 13 tiles: two rounds of the 8 waves
+constexpr int U16_THREADS = 512;
+constexpr int U16_MAX_GROUPS = (((U16_MAX_T * HOP - 1) + NFFT + 3) / 4 + U16_THREADS - 1) / U16_THREADS;
+constexpr int A2_BYTES = 16 * 1024;
+constexpr int SCRATCH_FLOATS = 64;      // [0..15] wave maxima of the log-mel rows, [16..23] of |x|
+constexpr int LDS_LIMIT = 160 * 1024;
+constexpr float XMAX = 16.f;
+constexpr double A1SCALE = 32.0, A2SCALE = 32.0;
+constexpr float YSCALE = 1.0f / 256.0f;
+constexpr double PSCALE = 1.0 / 16777216.0;      // (2^10 * 32 * 2^-8 * 32)^-2
+constexpr int NPROB = 8;                // k1 = 1..7 and the pair of reals (k1 = 0, 8)
+constexpr int MEL_TILES = 5;
+// one device table: [A1: 25 n2 x (hi, lo)] [A2: 16 fragments] [A2 of the real pair: 16] [mel: 8 problems x 5 tiles x (W1, W2)], 1 KB each
+constexpr int T_A1 = 0, T_A2 = 2 * NN2, T_A2S = T_A2 + 16, T_MEL = T_A2S + 16, T_FRAGS = T_MEL + NPROB * MEL_TILES * 2;
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) char* gptr_t;
+
+struct U16Args {
+  const float* wav; int B; int n; int T;
+  const long long* starts; long long n_total;
+  const char* tables;
+  int n_mels; int pad_mode; int log_mode; float log_eps; float top_db; int use_floor; int mean_norm;
+  float* out; int ld_out;
+  unsigned inv_mels;
+};
+
+#ifdef SD_STAMP
+__device__ unsigned long long g_utt16_stamps[1024][8][16];
+#define U16_STAMP(i) do { if (blockIdx.x >= 4096 && blockIdx.x < 5120 && lane == 0) g_utt16_stamps[blockIdx.x - 4096][wid][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define U16_STAMP(i) do { } while (0)
+#endif
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__host__ __device__ constexpr int img_words(int n) { return (n + NFFT) + (n + NFFT) / HOP + 1; }
+
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {      // 16-lane rows 1, 3 of a <-> rows 0, 2 of b
+  const auto w = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  const unsigned w0 = w[0], w1 = w[1];
+  a = w0; b = w1;
+}
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {      // rows 2, 3 of a <-> rows 0, 1 of b
+  const auto w = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  const unsigned w0 = w[0], w1 = w[1];
+  a = w0; b = w1;
+}
+// r[i] holds in lane group g the value (i, g)  ->  r[i] holds in lane group g the value (g, i)
+__device__ __forceinline__ void transpose4(unsigned (&r)[4]) {
+  swap16(r[0], r[1]);
+  swap16(r[2], r[3]);
+  swap32(r[0], r[2]);
+  swap32(r[1], r[3]);
+}
+
+__device__ __forceinline__ unsigned pk_rtz(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+__device__ __forceinline__ float f16lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)); }
+__device__ __forceinline__ float f16hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+__device__ __forceinline__ h8v frag_of(unsigned a, unsigned b, unsigned c, unsigned d) {
+  const u32x4 v = {a, b, c, d};
+  return __builtin_bit_cast(h8v, v);
+}
+template <typename V>
+__device__ __forceinline__ V gfrag(gptr_t base, unsigned lane16, int frag) {      // uniform base + 32-bit lane offset (see sd_fbank_utt.hip)
+  return *reinterpret_cast<const __attribute__((address_space(1))) V*>(base + (size_t)frag * 1024 + lane16);
+}
+
+// One stage-2 problem: C2[u] (16 outputs x 16 frames each, u = 0..3) = A2 (64 x 64, fragments (u, s, hi | lo) at index (u * 2 + s) * 2 + part)
+// times the problem's split sums; then the 8 powers this lane holds, split into two bf16 halves (packed: 4 + 4 registers).
+// LDSA: the matrix fragments come from LDS (a2 + 16 lane); else from global memory (the pair of reals: its own matrix, once per tile).
+template <bool LDSA>
+__device__ __forceinline__ void u16_problem(const char* a2l, gptr_t a2g, unsigned lane16, const unsigned (&yh)[NBLK], const unsigned (&yl)[NBLK],
+                                            unsigned (&p1)[4], unsigned (&p2)[4]) {
+  auto afrag = [&](int idx) -> h8v {
+    if constexpr (LDSA) return *reinterpret_cast<const h8v*>(a2l + idx * 1024);
+    else return gfrag<h8v>(a2g, lane16, idx);
+  };
+  f32x4 c2[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) c2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  h8v ah = afrag(0), al = afrag(1);
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {                    // (s, u) = (st >> 2, st & 3): the B fragment changes once
+    const int s = st >> 2, u = st & 3;
+    const h8v bh = frag_of(yh[4 * s], yh[4 * s + 1], yh[4 * s + 2], s == 0 ? yh[3] : 0u);
+    const h8v bl = frag_of(yl[4 * s], yl[4 * s + 1], yl[4 * s + 2], s == 0 ? yl[3] : 0u);
+    h8v nh = ah, nl = al;
+    if (st + 1 < 8) {
+      const int s1 = (st + 1) >> 2, u1 = (st + 1) & 3;
+      nh = afrag((u1 * 2 + s1) * 2);
+      nl = afrag((u1 * 2 + s1) * 2 + 1);
+    }
+    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c2[u], 0, 0, 0);
+    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c2[u], 0, 0, 0);
+    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c2[u], 0, 0, 0);
+    ah = nh; al = nl;
+  }
+  // rows 4 g + r of tile u: r = 2 q + part -> output idx = 2 g + q + 8 u; power of output (u, q) = element 2 u + q of the mel product's B fragment
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float pa = c2[u][0] * c2[u][0] + c2[u][1] * c2[u][1];
+    const float pb = c2[u][2] * c2[u][2] + c2[u][3] * c2[u][3];
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 h;
+    h[0] = (__bf16)pa; h[1] = (__bf16)pb;
+    bf2 l;
+    l[0] = (__bf16)(pa - (float)h[0]); l[1] = (__bf16)(pb - (float)h[1]);
+    p1[u] = __builtin_bit_cast(unsigned, h);
+    p2[u] = __builtin_bit_cast(unsigned, l);
+  }
+}
+
+__global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* const a2s = smem_raw;                                                        // stage-2 matrix fragments (16 KB); later the column sums
+  float* const scratch = reinterpret_cast<float*>(smem_raw + A2_BYTES);
+  unsigned* const img = reinterpret_cast<unsigned*>(smem_raw + A2_BYTES + SCRATCH_FLOATS * 4);    // split samples; later the log-mel rows
+  float* const lm = reinterpret_cast<float*>(img);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.x;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const gptr_t tab = (gptr_t)p.tables;
+
+  int kexp = 10;
+  U16_STAMP(0);
+  // ---- stage-2 matrix -> LDS; wave maxima reset
+#pragma unroll
+  for (int i = 0; i < A2_BYTES / (U16_THREADS * 16); ++i)
+    *reinterpret_cast<u32x4*>(a2s + (i * U16_THREADS + tid) * 16) =
+        *reinterpret_cast<const u32x4*>(p.tables + (size_t)T_A2 * 1024 + (i * U16_THREADS + tid) * 16);
+  if (tid < 16) scratch[tid] = -INFINITY;
+
+  // ---- the padded signal -> LDS, exactly as in sd_fbank_utt.hip (clamped, scaled by the utterance's 2^k, split into two f16 halves,
+  // word i + i / 160), with 512 threads
+  const int L = p.n + NFFT;
+  {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const long long start = p.starts ? p.starts[b] : (long long)b * p.n;
+    auto group_inner = [&](int g) -> bool {
+      const int i = 4 * g;
+      const long long gi = start + i - NFFT / 2;
+      return i >= NFFT / 2 && i + 3 < NFFT / 2 + p.n && gi >= 0 && gi + 3 < p.n_total;
+    };
+    f32x4 v[U16_MAX_GROUPS];
+    float amax = 0.f;
+#pragma unroll
+    for (int u = 0; u < U16_MAX_GROUPS; ++u) {
+      const int g = tid + U16_THREADS * u;
+      const bool in = group_inner(g);
+      const f32x4 x = *reinterpret_cast<const f32x4u*>(p.wav + (in ? start + 4 * g - NFFT / 2 : 0));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[u][c] = in ? x[c] : 0.f;
+    }
+    const bool hang = start < 0 || start + p.n > p.n_total;
+    auto edge_range = [&](int lo, int hi, auto&& fn) {
+      for (int i = lo + tid; i < hi; i += U16_THREADS)
+        if (!group_inner(i >> 2)) fn(i);
+    };
+    auto edges = [&](auto&& fn) {
+      if (hang) { edge_range(0, L, fn); }
+      else { edge_range(0, NFFT / 2 + 4 < L ? NFFT / 2 + 4 : L, fn); edge_range(NFFT / 2 + p.n - 4 > NFFT / 2 + 4 ? NFFT / 2 + p.n - 4 : NFFT / 2 + 4, L, fn); }
+    };
+    edges([&](int i) {
+      int sidx = i - NFFT / 2;
+      bool ok = true;
+      if (p.pad_mode == SD_PAD_REFLECT) {
+        sidx = sidx < 0 ? -sidx : sidx;
+        sidx = sidx >= p.n ? 2 * (p.n - 1) - sidx : sidx;
+      } else {
+        ok = sidx >= 0 && sidx < p.n;
+      }
+      sidx = sidx < 0 ? 0 : (sidx >= p.n ? p.n - 1 : sidx);
+      long long gi = start + sidx;
+      ok = ok && gi >= 0 && gi < p.n_total;
+      gi = gi < 0 ? 0 : (gi >= p.n_total ? p.n_total - 1 : gi);
+      float x = p.wav[gi];
+      x = ok ? __builtin_amdgcn_fmed3f(x, -XMAX, XMAX) : 0.f;
+      amax = fmaxf(amax, fabsf(x));
+      img[i + i / HOP] = __float_as_uint(x);
+    });
+#pragma unroll
+    for (int u = 0; u < U16_MAX_GROUPS; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        v[u][c] = __builtin_amdgcn_fmed3f(v[u][c], -XMAX, XMAX);
+        amax = fmaxf(amax, fabsf(v[u][c]));
+      }
+    amax = sd_wave_max(amax);
+    if (lane == 0) scratch[16 + wid] = amax;
+    U16_STAMP(1);
+    __syncthreads();
+    float mx = scratch[16];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, scratch[16 + i]);
+    const int e = (int)((__float_as_uint(mx) >> 23) & 0xFFu) - 126;
+    if (mx >= 1e-30f) kexp = 14 - e;
+    const float xs = __uint_as_float((unsigned)(kexp + 127) << 23);
+    auto split = [&](float x) -> unsigned {
+      const _Float16 hi = (_Float16)x;
+      const _Float16 lo = (_Float16)(x - (float)hi);
+      return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    };
+#pragma unroll
+    for (int u = 0; u < U16_MAX_GROUPS; ++u) {
+      const int g = tid + U16_THREADS * u;
+      if (group_inner(g)) {
+        unsigned* const dst = img + 4 * g + (4 * g) / HOP;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[c] = split(xs * v[u][c]);
+      }
+    }
+    edges([&](int i) {
+      unsigned* const w = img + i + i / HOP;
+      *w = split(xs * __uint_as_float(*w));
+    });
+  }
+  const float pback = __uint_as_float((unsigned)(10 - kexp + 127) << 23);
+  U16_STAMP(2);
+  __syncthreads();
+  U16_STAMP(3);
+
+  const int ntiles = (p.T + FT - 1) / FT;
+  const int j = lane & 15, g = lane >> 4;
+  const int hx = g & 1;                               // lane groups 2, 3 read what 0, 1 read: their half of the stage-1 matrix is zero
+
+#pragma unroll 1
+  for (int round = 0; round < 2; ++round) {
+    gptr_t tb = tab;
+    asm volatile("" : "+s"(tb));                      // (per round: keeps the fragment addresses base + constant out of the loop preheader)
+    const int tile = wid + 8 * round;
+    const bool active = tile < ntiles;                // wave-uniform
+    const int f0 = tile * FT;
+    int nvalid = p.T - f0; nvalid = nvalid > FT ? FT : nvalid;
+    const int f = f0 + (j < nvalid ? j : 0);
+    const unsigned* const x0 = img + 161 * f + 201 * hx;     // word of x[200 hx]; x[200 hx + m] at x0 + m + [m >= (hx ? 120 : 160)]
+    const unsigned* const xm = x0 + hx;
+    // split stage-1 sums: [n2] x {hi, lo} x {components 0-1, 2-3} of this lane group's pair; n2 = 25..27 padding
+    unsigned yh01[4 * NBLK], yl01[4 * NBLK], yh23[4 * NBLK], yl23[4 * NBLK];
+    if (active) {
+      // ---- stage 1: per n2 three MFMAs (hi.hi + hi.lo + lo.hi); the matrix fragments of n2 + 3 and the signal words of n2 + 1 are requested
+      // ahead, the previous n2's sums are split while this one's MFMAs run
+      h8v ah[4], al[4];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { ah[i] = gfrag<h8v>(tb, lane16, T_A1 + 2 * i); al[i] = gfrag<h8v>(tb, lane16, T_A1 + 2 * i + 1); }
+      auto xword = [&](int e, int n2) -> unsigned {
+        const int m = 25 * e + n2;
+        return m < 120 ? x0[m] : (m < 160 ? xm[m] : x0[m + 1]);
+      };
+      unsigned d[2][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[0][e] = xword(e, 0);
+      f32x4 c1[2];
+      static_for<0, NN2 + 1>([&](auto n2c) {
+        constexpr int n2 = decltype(n2c)::value;
+        if constexpr (n2 < NN2) {
+          if constexpr (n2 + 3 < NN2) { ah[(n2 + 3) & 3] = gfrag<h8v>(tb, lane16, T_A1 + 2 * (n2 + 3)); al[(n2 + 3) & 3] = gfrag<h8v>(tb, lane16, T_A1 + 2 * (n2 + 3) + 1); }
+          if constexpr (n2 + 1 < NN2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[(n2 + 1) & 1][e] = xword(e, n2 + 1);
+          }
+          const unsigned* dd = d[n2 & 1];
+          const h8v xh = frag_of(__builtin_amdgcn_perm(dd[1], dd[0], 0x05040100u), __builtin_amdgcn_perm(dd[3], dd[2], 0x05040100u),
+                                 __builtin_amdgcn_perm(dd[5], dd[4], 0x05040100u), __builtin_amdgcn_perm(dd[7], dd[6], 0x05040100u));
+          const h8v xl = frag_of(__builtin_amdgcn_perm(dd[1], dd[0], 0x07060302u), __builtin_amdgcn_perm(dd[3], dd[2], 0x07060302u),
+                                 __builtin_amdgcn_perm(dd[5], dd[4], 0x07060302u), __builtin_amdgcn_perm(dd[7], dd[6], 0x07060302u));
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[n2 & 3], xh, z, 0, 0, 0);
+          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[n2 & 3], xl, z, 0, 0, 0);
+          c1[n2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[n2 & 3], xh, z, 0, 0, 0);
+        }
+        if constexpr (n2 > 0) {
+          const f32x4& c = c1[(n2 - 1) & 1];
+          const float a0 = YSCALE * c[0], a1 = YSCALE * c[1], a2 = YSCALE * c[2], a3 = YSCALE * c[3];
+          const unsigned h01 = pk_rtz(a0, a1), h23 = pk_rtz(a2, a3);
+          yh01[n2 - 1] = h01;
+          yl01[n2 - 1] = pk_rtz(a0 - f16lo(h01), a1 - f16hi(h01));
+          yh23[n2 - 1] = h23;
+          yl23[n2 - 1] = pk_rtz(a2 - f16lo(h23), a3 - f16hi(h23));
+        }
+        __builtin_amdgcn_sched_barrier(0);            // one n2 at a time: left alone, the scheduler pulls the reads of many steps forward and spills the sums
+      });
+#pragma unroll
+      for (int i = NN2; i < 4 * NBLK; ++i) { yh01[i] = 0u; yl01[i] = 0u; yh23[i] = 0u; yl23[i] = 0u; }
+    }
+    U16_STAMP(4 + 4 * round);
+    // the log-mel rows of the first eight tiles overwrite signal words that only those tiles' stage 1 reads
+    if (round == 0) __syncthreads();
+    if (active) {
+      // ---- registers <-> lane groups: block m (n2 = 4 m + i in register i, pair g in lane group g) -> pair i in register i, n2 = 4 m + g in
+      // lane group g.  After it, element m of array P<kind>[i] is pair i's k-step data: P..[i][m] for m = 4 s .. 4 s + 3 = B fragment of step s
+      unsigned Ph01[4][NBLK], Pl01[4][NBLK], Ph23[4][NBLK], Pl23[4][NBLK];
+#pragma unroll
+      for (int m = 0; m < NBLK; ++m) {
+        unsigned r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = yh01[4 * m + i];
+        transpose4(r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ph01[i][m] = r[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = yl01[4 * m + i];
+        transpose4(r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Pl01[i][m] = r[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = yh23[4 * m + i];
+        transpose4(r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ph23[i][m] = r[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = yl23[4 * m + i];
+        transpose4(r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Pl23[i][m] = r[i];
+      }
+      U16_STAMP(5 + 4 * round);
+      // ---- stage 2: problem 2 i = components 0-1 of pair i, problem 2 i + 1 = components 2-3 (pair 3: the two reals, own matrix)
+      unsigned pw1[NPROB][4], pw2[NPROB][4];
+      const char* const a2l = a2s + lane16;
+      const gptr_t a2g = tb + (size_t)T_A2S * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u16_problem<true>(a2l, a2g, lane16, Ph01[i], Pl01[i], pw1[2 * i], pw2[2 * i]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < 3) u16_problem<true>(a2l, a2g, lane16, Ph23[i], Pl23[i], pw1[2 * i + 1], pw2[2 * i + 1]);
+        else u16_problem<false>(a2l, a2g, lane16, Ph23[i], Pl23[i], pw1[2 * i + 1], pw2[2 * i + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      U16_STAMP(6 + 4 * round);
+      // ---- mel: 5 row tiles x 8 problems, one K = 32 step each, split bf16 (W1 P1 + W1 P2 + W2 P1); weights streamed from L2, four fragment
+      // pairs ahead
+      f32x4 mel[MEL_TILES];
+#pragma unroll
+      for (int t = 0; t < MEL_TILES; ++t) mel[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      constexpr int NW = MEL_TILES * NPROB;           // (t, problem) pairs in issue order: problem-major inside a tile
+      constexpr int AHEAD = 4;
+      bf8v w1[AHEAD], w2[AHEAD];
+      auto wfrag = [&](int it, int part) -> bf8v {
+        const int t = it / NPROB, pr = it % NPROB;
+        return gfrag<bf8v>(tb, lane16, T_MEL + (pr * MEL_TILES + t) * 2 + part);
+      };
+#pragma unroll
+      for (int it = 0; it < AHEAD; ++it) { w1[it] = wfrag(it, 0); w2[it] = wfrag(it, 1); }
+      static_for<0, NW>([&](auto itc) {
+        constexpr int it = decltype(itc)::value;
+        constexpr int t = it / NPROB, pr = it % NPROB;
+        const bf8v a1 = w1[it % AHEAD], a2w = w2[it % AHEAD];
+        const bf8v b1 = __builtin_bit_cast(bf8v, (u32x4{pw1[pr][0], pw1[pr][1], pw1[pr][2], pw1[pr][3]}));
+        const bf8v b2 = __builtin_bit_cast(bf8v, (u32x4{pw2[pr][0], pw2[pr][1], pw2[pr][2], pw2[pr][3]}));
+        mel[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, mel[t], 0, 0, 0);
+        mel[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, mel[t], 0, 0, 0);
+        mel[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2w, b1, mel[t], 0, 0, 0);
+        if constexpr (it + AHEAD < NW) { w1[it % AHEAD] = wfrag(it + AHEAD, 0); w2[it % AHEAD] = wfrag(it + AHEAD, 1); }
+      });
+      // ---- log, utterance maximum, rows -> LDS (no branches: what does not exist goes to a spare word and counts as -inf)
+      const bool ln = p.log_mode == SD_LOG_LN_EPS;
+      const float lscale = ln ? 0.6931471805599453f : 3.0102999566398120f;      // v_log_f32 is log2
+      float vmax = -INFINITY;
+      float* const mrow = lm + (size_t)(f0 + j) * MELP;
+      float* const spare = scratch + 32 + (lane & 31);
+      const bool jok = j < nvalid;
+#pragma unroll
+      for (int t = 0; t < MEL_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * t + 4 * g + r;
+          const bool ok = jok && m < p.n_mels;
+          const float v = mel[t][r] * pback * pback;
+          const float lv = lscale * __builtin_amdgcn_logf(ln ? v + p.log_eps : fmaxf(v, p.log_eps));
+          *(ok ? mrow + m : spare) = lv;
+          vmax = fmaxf(vmax, ok ? lv : -INFINITY);
+        }
+      vmax = sd_wave_max(vmax);
+      if (lane == 0) scratch[round * 8 + wid] = vmax;
+      U16_STAMP(7 + 4 * round);
+    }
+  }
+  __syncthreads();
+  U16_STAMP(14);
+
+  // ---- top_db floor relative to the utterance maximum, mean over T per mel bin, the one write of the output
+  float thr = -INFINITY;
+  if (p.use_floor) {
+    float mx = scratch[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, scratch[i]);
+    thr = mx - p.top_db;
+  }
+  float* const part = reinterpret_cast<float*>(a2s);          // (the stage-2 matrix is dead) [24][96] partial column sums, then [96] means behind them
+  float* const mean = part + 24 * 96;
+  if (p.mean_norm) {
+    const int per_row = (p.n_mels + 3) >> 2;
+    int RG = U16_THREADS / per_row; RG = RG > 24 ? 24 : RG;
+    const int rg = tid / per_row, c0 = (tid - rg * per_row) * 4;
+    if (rg < RG) {
+      float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+      int t = rg;
+      for (; t + RG < p.T; t += 2 * RG) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c0 + c < p.n_mels) { s0[c] += fmaxf(lm[t * MELP + c0 + c], thr); s1[c] += fmaxf(lm[(t + RG) * MELP + c0 + c], thr); }
+      }
+      if (t < p.T) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c0 + c < p.n_mels) s0[c] += fmaxf(lm[t * MELP + c0 + c], thr);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c0 + c < p.n_mels) part[rg * 96 + c0 + c] = s0[c] + s1[c];
+    }
+    __syncthreads();
+    if (tid < p.n_mels) {
+      float sum = 0.f;
+      for (int k = 0; k < RG; ++k) sum += part[k * 96 + tid];
+      mean[tid] = sum / (float)p.T;
+    }
+    __syncthreads();
+  }
+  float* const orow = p.out + (size_t)b * p.T * p.ld_out;
+  if ((p.n_mels & 3) == 0 && (p.ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15u) == 0) {
+    const int per_row = p.n_mels >> 2;
+    const int total = p.T * per_row;
+    const unsigned inv = p.inv_mels;
+#pragma unroll 4
+    for (int e = tid; e < total; e += U16_THREADS) {
+      const int t = (int)__umulhi((unsigned)e, inv);
+      const int c = (e - t * per_row) * 4;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(lm[t * MELP + c + i], thr) - (p.mean_norm ? mean[c + i] : 0.f);
+      *reinterpret_cast<f32x4*>(orow + (size_t)t * p.ld_out + c) = v;
+    }
+  } else {
+    const int total = p.T * p.n_mels;
+    for (int e = tid; e < total; e += U16_THREADS) {
+      const int t = e / p.n_mels, c = e - t * p.n_mels;
+      orow[(size_t)t * p.ld_out + c] = fmaxf(lm[t * MELP + c], thr) - (p.mean_norm ? mean[c] : 0.f);
+    }
+  }
+  U16_STAMP(15);
+}
+
+size_t u16_lds_bytes(int n, int T) {
+  const size_t words = (size_t)img_words(n) > (size_t)T * MELP ? (size_t)img_words(n) : (size_t)T * MELP;
+  return (size_t)A2_BYTES + SCRATCH_FLOATS * 4 + words * 4;
+}
+
+unsigned short bf16_bits(float v) {
+  unsigned u;
+  std::memcpy(&u, &v, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+float bf16_value(unsigned short b) {
+  const unsigned u = (unsigned)b << 16;
+  float v;
+  std::memcpy(&v, &u, 4);
+  return v;
+}
+
+// what row (lane group G, component c) of the stage-1 product is: k1 and re / im, or one of the two reals
+struct RowOf { int k1; int kind; };      // kind 0: re, 1: im, 2: Y[0] (real), 3: rho (Y[8] rotated to the real axis)
+RowOf row_of(int G, int c) {
+  if (G < 3) return RowOf{1 + 2 * G + (c >> 1), c & 1};
+  if (c < 2) return RowOf{7, c};
+  return RowOf{c == 2 ? 0 : 8, c};
+}
+
+}  // namespace
+
+#ifdef SD_STAMP
+extern "C" int sd_debug_read_utt16_stamps(unsigned long long* host, int n) {
+  SD_CHECK_ARG(host && n == 1024 * 8 * 16, "sd_debug_read_utt16_stamps: need 131072 entries");
+  SD_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_utt16_stamps), sizeof(unsigned long long) * n));
+  return SD_OK;
+}
+#endif
+
+int sd_fbank_utt16_create_tables(sd_fbank_plan* plan, const float* window, const float* mel_fb) {
+  const int n_mels = plan->n_mels;
+  std::vector<unsigned short> tab((size_t)T_FRAGS * 512);
+  auto put_f16 = [&](size_t frag_hi, size_t frag_lo, int l, int e, double v) {
+    const _Float16 hi = (_Float16)(float)v;
+    const _Float16 lo = (_Float16)(float)(v - (double)(float)hi);
+    tab[frag_hi * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, hi);
+    tab[frag_lo * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, lo);
+  };
+  // stage 1: A operand of v_mfma_f32_16x16x32_f16: lane l holds row l & 15, k = 8 (l >> 4) + e = n1 (k >= 16: zero)
+  for (int n2 = 0; n2 < NN2; ++n2)
+    for (int l = 0; l < 64; ++l)
+      for (int e = 0; e < 8; ++e) {
+        const int rho = l & 15, k = 8 * (l >> 4) + e;
+        double v = 0.0;
+        if (k < 16) {
+          const int n = 25 * k + n2;
+          const RowOf r = row_of(rho >> 2, rho & 3);
+          const double ang = 2.0 * M_PI * (double)(((long)r.k1 * n) % NFFT) / (double)NFFT;
+          const double w = A1SCALE * (double)window[n];
+          if (r.kind == 0) v = w * std::cos(ang);
+          else if (r.kind == 1) v = -w * std::sin(ang);
+          else if (r.kind == 2) v = w;
+          else v = w * std::cos(ang - M_PI * (double)n2 / 25.0);
+        }
+        put_f16(T_A1 + 2 * n2, T_A1 + 2 * n2 + 1, l, e, v);
+      }
+  // stage 2: fragment (u, s): rows 16 u + (l & 15): r = row & 3 = 2 q + out part, output idx = 2 (row >> 2 & 3) + q + 8 u;
+  // k = 8 (l >> 4) + e: m' = e >> 1, in part = e & 1, n2 = 4 (4 s + m') + (l >> 4)
+  for (int special = 0; special < 2; ++special)
+    for (int u = 0; u < 4; ++u)
+      for (int s = 0; s < 2; ++s)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 8; ++e) {
+            const int rho = l & 15, Go = rho >> 2, r = rho & 3;
+            const int idx = 2 * Go + (r >> 1) + 8 * u, oim = r & 1;
+            const int n2 = 4 * (4 * s + (e >> 1)) + (l >> 4), yim = e & 1;
+            double v = 0.0;
+            if (n2 < NN2) {
+              if (!special) {
+                if (idx < NN2) {
+                  const double th = 2.0 * M_PI * (double)((n2 * idx) % NN2) / (double)NN2;
+                  v = oim == 0 ? (yim == 0 ? std::cos(th) : std::sin(th)) : (yim == 0 ? -std::sin(th) : std::cos(th));
+                }
+              } else if (idx <= 12) {                 // k1 = 0: X[16 idx] from the real Y[0, n2] (in part 0)
+                const double th = 2.0 * M_PI * (double)((n2 * idx) % NN2) / (double)NN2;
+                if (yim == 0) v = oim == 0 ? std::cos(th) : -std::sin(th);
+              } else if (idx <= 25) {                 // k1 = 8: X[8 + 16 k2], k2 = idx - 13, from rho[n2] (in part 1): e^{-i pi n2 (2 k2 + 1) / 25}
+                const double ph = M_PI * (double)((n2 * (2 * (idx - 13) + 1)) % 50) / 25.0;
+                if (yim == 1) v = oim == 0 ? std::cos(ph) : -std::sin(ph);
+              }
+            }
+            const size_t base = (special ? T_A2S : T_A2) + (size_t)(u * 2 + s) * 2;
+            put_f16(base, base + 1, l, e, A2SCALE * v);
+          }
+  // mel weights: problem pr = 2 i + (components 2-3 ? 1 : 0) of pair i; lane l holds row (mel) 16 t + (l & 15), k = 8 (l >> 4) + e:
+  // u = e >> 1, q = e & 1, output idx = 2 (l >> 4) + q + 8 u of the problem
+  for (int pr = 0; pr < NPROB; ++pr)
+    for (int t = 0; t < MEL_TILES; ++t)
+      for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 8; ++e) {
+          const int m = 16 * t + (l & 15), idx = 2 * (l >> 4) + (e & 1) + 8 * (e >> 1);
+          int bin = -1;
+          if (pr < 7) {
+            const int k1 = pr + 1;                    // pairs: (1, 2), (3, 4), (5, 6), (7, reals)
+            if (idx <= 12) bin = k1 + 16 * idx;
+            else if (idx <= 24) bin = 16 - k1 + 16 * (24 - idx);
+          } else {
+            if (idx <= 12) bin = 16 * idx;
+            else if (idx <= 25) bin = 8 + 16 * (idx - 13);
+          }
+          float w = 0.f;
+          if (bin >= 0 && bin < NFREQ && m < n_mels) w = (float)((double)mel_fb[(size_t)bin * n_mels + m] * PSCALE);
+          const unsigned short w1 = bf16_bits(w);
+          const size_t f0 = T_MEL + (size_t)(pr * MEL_TILES + t) * 2;
+          tab[f0 * 512 + l * 8 + e] = w1;
+          tab[(f0 + 1) * 512 + l * 8 + e] = bf16_bits(w - bf16_value(w1));
+        }
+  plan->utt16_tables_dev = nullptr;
+  hipError_t e = hipMalloc(&plan->utt16_tables_dev, (size_t)T_FRAGS * 1024);
+  if (e == hipSuccess) e = hipMemcpy(plan->utt16_tables_dev, tab.data(), (size_t)T_FRAGS * 1024, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    sd_fbank_utt16_destroy_tables(plan);
+    return sd_set_error(SD_ERR_HIP, "sd_fbank_plan_create: device table upload failed: %s", hipGetErrorString(e));
+  }
+  return SD_OK;
+}
+
+void sd_fbank_utt16_destroy_tables(sd_fbank_plan* plan) {
+  if (plan->utt16_tables_dev) (void)hipFree(plan->utt16_tables_dev);
+  plan->utt16_tables_dev = nullptr;
+}
+
+bool sd_fbank_utt16_supported(const sd_fbank_plan* plan, int n) {
+  static const int which = [] { const char* e = sd_experiment_env("SD_FBANK_UTT"); return e ? atoi(e) : 16; }();   // A/B: 0 folded kernel, 32 the 32-frame-tile kernel
+  if (which != 16 || !plan->utt16_tables_dev) return false;
+  const int T = 1 + n / HOP;
+  return T <= U16_MAX_T && u16_lds_bytes(n, T) <= (size_t)LDS_LIMIT;
+}
+
+int sd_fbank_utt16_launch(const sd_fbank_plan* plan, const float* wav_dev, long long n_total, const long long* starts_dev, int B, int n,
+                          int mean_norm, float* out_dev, int ld_out, hipStream_t stream) {
+  const int T = 1 + n / HOP;
+  U16Args a;
+  a.wav = wav_dev; a.B = B; a.n = n; a.T = T;
+  a.starts = starts_dev; a.n_total = n_total;
+  a.tables = static_cast<const char*>(plan->utt16_tables_dev);
+  a.n_mels = plan->n_mels; a.pad_mode = plan->pad_mode; a.log_mode = plan->log_mode; a.log_eps = plan->log_eps;
+  a.top_db = plan->top_db;
+  a.use_floor = plan->log_mode == SD_LOG_DB_TOPDB && plan->top_db >= 0.f;
+  a.mean_norm = mean_norm;
+  a.out = out_dev; a.ld_out = ld_out;
+  const int per_row = plan->n_mels % 4 == 0 ? plan->n_mels / 4 : plan->n_mels;
+  a.inv_mels = (unsigned)((((unsigned long long)1 << 32) + per_row - 1) / per_row);
+  const size_t lds = u16_lds_bytes(n, T);
+  SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(fbank_utt16_kernel), LDS_LIMIT));
+  {
+    SdProfScope prof(SD_PROF_FBANK, stream, (double)B * ((double)n * 4.0 + (double)T * plan->n_mels * 4.0));
+    hipLaunchKernelGGL(fbank_utt16_kernel, dim3((unsigned)B), dim3(U16_THREADS), lds, stream, a);
+  }
+  SD_CHECK_LAUNCH("fbank_utt16_kernel");
+  return SD_OK;
+}
