@@ -38,6 +38,7 @@ constexpr int U16_MAX_T = 208;          // 13 tiles: two rounds of the 8 waves
 constexpr int U16_THREADS = 512;
 constexpr int U16_MAX_GROUPS = (((U16_MAX_T * HOP - 1) + NFFT + 3) / 4 + U16_THREADS - 1) / U16_THREADS;
 constexpr int A2_BYTES = 16 * 1024;
+constexpr int RING_BYTES = 16 * 1024;   // two chunks of eight 1 KB fragments: the streamed tables, shared by the eight waves
 constexpr int SCRATCH_FLOATS = 64;      // [0..15] wave maxima of the log-mel rows, [16..23] of |x|
 constexpr int LDS_LIMIT = 160 * 1024;
 constexpr float XMAX = 16.f;
@@ -46,8 +47,14 @@ constexpr float YSCALE = 1.0f / 256.0f;
 constexpr double PSCALE = 1.0 / 16777216.0;      // (2^10 * 32 * 2^-8 * 32)^-2
 constexpr int NPROB = 8;                // k1 = 1..7 and the pair of reals (k1 = 0, 8)
 constexpr int MEL_TILES = 5;
-// one device table: [A1: 25 n2 x (hi, lo)] [A2: 16 fragments] [A2 of the real pair: 16] [mel: 8 problems x 5 tiles x (W1, W2)], 1 KB each
-constexpr int T_A1 = 0, T_A2 = 2 * NN2, T_A2S = T_A2 + 16, T_MEL = T_A2S + 16, T_FRAGS = T_MEL + NPROB * MEL_TILES * 2;
+// one device table of 1 KB fragments: [A2: 16, LDS resident] then the STREAM in the order a tile round consumes it, eight fragments
+// (= four items of a hi / lo or W1 / W2 pair) per chunk: [A1: 25 n2 x (hi, lo), padded to 56] [A2 of the real pair: 16] [mel: 8 problems x 5
+// tiles x (W1, W2)]
+constexpr int T_A2 = 0, T_STREAM = 16;
+constexpr int S_A1 = 0, S_A2S = 56, S_MEL = 72, S_FRAGS = S_MEL + NPROB * MEL_TILES * 2;      // stream-relative
+constexpr int NCHUNK = S_FRAGS / 8;     // 19
+static_assert(S_FRAGS % 8 == 0 && S_A2S % 8 == 0 && S_MEL % 8 == 0, "chunks of eight fragments");
+constexpr int T_FRAGS = T_STREAM + S_FRAGS;
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
@@ -110,37 +117,9 @@ __device__ __forceinline__ V gfrag(gptr_t base, unsigned lane16, int frag) {    
   return *reinterpret_cast<const __attribute__((address_space(1))) V*>(base + (size_t)frag * 1024 + lane16);
 }
 
-// One stage-2 problem: C2[u] (16 outputs x 16 frames each, u = 0..3) = A2 (64 x 64, fragments (u, s, hi | lo) at index (u * 2 + s) * 2 + part)
-// times the problem's split sums; then the 8 powers this lane holds, split into two bf16 halves (packed: 4 + 4 registers).
-// LDSA: the matrix fragments come from LDS (a2 + 16 lane); else from global memory (the pair of reals: its own matrix, once per tile).
-template <bool LDSA>
-__device__ __forceinline__ void u16_problem(const char* a2l, gptr_t a2g, unsigned lane16, const unsigned (&yh)[NBLK], const unsigned (&yl)[NBLK],
-                                            unsigned (&p1)[4], unsigned (&p2)[4]) {
-  auto afrag = [&](int idx) -> h8v {
-    if constexpr (LDSA) return *reinterpret_cast<const h8v*>(a2l + idx * 1024);
-    else return gfrag<h8v>(a2g, lane16, idx);
-  };
-  f32x4 c2[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) c2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  h8v ah = afrag(0), al = afrag(1);
-#pragma unroll
-  for (int st = 0; st < 8; ++st) {                    // (s, u) = (st >> 2, st & 3): the B fragment changes once
-    const int s = st >> 2, u = st & 3;
-    const h8v bh = frag_of(yh[4 * s], yh[4 * s + 1], yh[4 * s + 2], s == 0 ? yh[3] : 0u);
-    const h8v bl = frag_of(yl[4 * s], yl[4 * s + 1], yl[4 * s + 2], s == 0 ? yl[3] : 0u);
-    h8v nh = ah, nl = al;
-    if (st + 1 < 8) {
-      const int s1 = (st + 1) >> 2, u1 = (st + 1) & 3;
-      nh = afrag((u1 * 2 + s1) * 2);
-      nl = afrag((u1 * 2 + s1) * 2 + 1);
-    }
-    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c2[u], 0, 0, 0);
-    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c2[u], 0, 0, 0);
-    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c2[u], 0, 0, 0);
-    ah = nh; al = nl;
-  }
-  // rows 4 g + r of tile u: r = 2 q + part -> output idx = 2 g + q + 8 u; power of output (u, q) = element 2 u + q of the mel product's B fragment
+// the 8 powers a lane holds of one problem (rows 4 g + r of tile u: r = 2 q + part -> output idx = 2 g + q + 8 u; power (u, q) = element
+// 2 u + q of the mel product's B fragment), split into two bf16 halves (packed: 4 + 4 registers)
+__device__ __forceinline__ void u16_powers(const f32x4 (&c2)[4], unsigned (&p1)[4], unsigned (&p2)[4]) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const float pa = c2[u][0] * c2[u][0] + c2[u][1] * c2[u][1];
@@ -155,11 +134,41 @@ __device__ __forceinline__ void u16_problem(const char* a2l, gptr_t a2g, unsigne
   }
 }
 
+// steps [ST0, ST1) of one stage-2 problem: C2[u] (16 outputs x 16 frames each, u = 0..3) += A2 (64 x 64; the fragment pair of step
+// (s, u) = (st >> 2, st & 3) at mat + (u * 2 + s) * 2 KB resp. + item(st) * 2 KB, hi then lo) times the problem's split sums
+template <int ST0, int ST1, typename AddrOf>
+__device__ __forceinline__ void u16_steps(AddrOf&& addr_of, const unsigned (&yh)[NBLK], const unsigned (&yl)[NBLK], f32x4 (&c2)[4]) {
+  static_assert((ST1 - ST0) % 2 == 0 && ST0 % 2 == 0, "steps go in pairs (u, u + 1) of one k step");
+  // two steps at a time, their three-MFMA chains interleaved (a dependent MFMA right behind its predecessor waits for the result);
+  // the next pair's four matrix fragments are requested in front of this pair's MFMAs
+  h8v ah0 = *reinterpret_cast<const h8v*>(addr_of(ST0)), al0 = *reinterpret_cast<const h8v*>(addr_of(ST0) + 1024);
+  h8v ah1 = *reinterpret_cast<const h8v*>(addr_of(ST0 + 1)), al1 = *reinterpret_cast<const h8v*>(addr_of(ST0 + 1) + 1024);
+#pragma unroll
+  for (int st = ST0; st < ST1; st += 2) {
+    const int s = st >> 2, u = st & 3;
+    const h8v bh = frag_of(yh[4 * s], yh[4 * s + 1], yh[4 * s + 2], s == 0 ? yh[3] : 0u);
+    const h8v bl = frag_of(yl[4 * s], yl[4 * s + 1], yl[4 * s + 2], s == 0 ? yl[3] : 0u);
+    h8v nh0 = ah0, nl0 = al0, nh1 = ah1, nl1 = al1;
+    if (st + 2 < ST1) {
+      nh0 = *reinterpret_cast<const h8v*>(addr_of(st + 2)); nl0 = *reinterpret_cast<const h8v*>(addr_of(st + 2) + 1024);
+      nh1 = *reinterpret_cast<const h8v*>(addr_of(st + 3)); nl1 = *reinterpret_cast<const h8v*>(addr_of(st + 3) + 1024);
+    }
+    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, c2[u], 0, 0, 0);
+    c2[u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, c2[u + 1], 0, 0, 0);
+    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, c2[u], 0, 0, 0);
+    c2[u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, c2[u + 1], 0, 0, 0);
+    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, c2[u], 0, 0, 0);
+    c2[u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, c2[u + 1], 0, 0, 0);
+    ah0 = nh0; al0 = nl0; ah1 = nh1; al1 = nl1;
+  }
+}
+
 __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   char* const a2s = smem_raw;                                                        // stage-2 matrix fragments (16 KB); later the column sums
-  float* const scratch = reinterpret_cast<float*>(smem_raw + A2_BYTES);
-  unsigned* const img = reinterpret_cast<unsigned*>(smem_raw + A2_BYTES + SCRATCH_FLOATS * 4);    // split samples; later the log-mel rows
+  char* const ring = smem_raw + A2_BYTES;                                            // streamed table fragments: 2 chunks x 8 KB
+  float* const scratch = reinterpret_cast<float*>(smem_raw + A2_BYTES + RING_BYTES);
+  unsigned* const img = reinterpret_cast<unsigned*>(smem_raw + A2_BYTES + RING_BYTES + SCRATCH_FLOATS * 4);    // split samples; later the log-mel rows
   float* const lm = reinterpret_cast<float*>(img);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.x;
@@ -267,73 +276,117 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
   const int ntiles = (p.T + FT - 1) / FT;
   const int j = lane & 15, g = lane >> 4;
   const int hx = g & 1;                               // lane groups 2, 3 read what 0, 1 read: their half of the stage-1 matrix is zero
+  // ---- the streamed tables.  Every wave of the workgroup needs the same fragments in the same order (stage-1 matrices, the real pair's
+  // stage-2 matrix, the mel weights: 152 KB per tile round).  Read per wave from L2 they were the bottleneck of this kernel (8 waves x
+  // 146 KB through the CU's 64 B/clk vector-memory path: ~18 k cycles per round, stamps); here they pass through a 16 KB LDS ring ONCE per
+  // round: chunk q = stream fragments 8 q .. 8 q + 7, wave w fetches fragment w by LDS-DMA, a workgroup barrier in front of each chunk's
+  // first use (19 per round) says "chunk q has landed, chunk q - 1 is no longer read", and every wave then requests its piece of chunk q + 1.
+  // Waves without a tile in a round still fetch and join the barriers.
+  const gptr_t stream = tab + (size_t)T_STREAM * 1024 + (size_t)wid * 1024 + lane16;
+  auto dma = [&](int q) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stream + (size_t)q * 8192),
+                                     (__attribute__((address_space(3))) void*)(ring + ((q & 1) * 8 + wid) * 1024), 16, 0, 0);
+  };
+  auto chunk_sync = [&](int q) {                      // in front of the first use of chunk q
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (q + 1 < NCHUNK) dma(q + 1);
+  };
+  // LDS address (+ 16 lane) of stream-relative item i (= fragments 2 i, 2 i + 1) of the current round
+  const char* const ringl = ring + lane16;
+  auto item = [&](int i) -> const char* { return ringl + ((((i >> 2) & 1) * 8) + 2 * (i & 3)) * 1024; };
 
+  const int nrounds = ntiles > 8 ? 2 : 1;
 #pragma unroll 1
-  for (int round = 0; round < 2; ++round) {
-    gptr_t tb = tab;
-    asm volatile("" : "+s"(tb));                      // (per round: keeps the fragment addresses base + constant out of the loop preheader)
+  for (int round = 0; round < nrounds; ++round) {
+    // A wave without a tile in this round computes on frame T - 1 and stores nothing: it has to walk the barriers anyway, its SIMD partner
+    // has a tile, and the round takes as long as the SIMD that carries two (no branches around the phases: fewer live ranges to merge)
     const int tile = wid + 8 * round;
-    const bool active = tile < ntiles;                // wave-uniform
     const int f0 = tile * FT;
-    int nvalid = p.T - f0; nvalid = nvalid > FT ? FT : nvalid;
-    const int f = f0 + (j < nvalid ? j : 0);
+    int nvalid = p.T - f0; nvalid = nvalid > FT ? FT : (nvalid < 0 ? 0 : nvalid);
+    int f = f0 + (j < nvalid ? j : 0); f = f < p.T ? f : p.T - 1;
     const unsigned* const x0 = img + 161 * f + 201 * hx;     // word of x[200 hx]; x[200 hx + m] at x0 + m + [m >= (hx ? 120 : 160)]
     const unsigned* const xm = x0 + hx;
+    __syncthreads();                                  // nobody reads the ring any more (previous round / the signal is staged)
+    dma(0);
     // split stage-1 sums: [n2] x {hi, lo} x {components 0-1, 2-3} of this lane group's pair; n2 = 25..27 padding
     unsigned yh01[4 * NBLK], yl01[4 * NBLK], yh23[4 * NBLK], yl23[4 * NBLK];
-    if (active) {
-      // ---- stage 1: per n2 three MFMAs (hi.hi + hi.lo + lo.hi); the matrix fragments of n2 + 3 and the signal words of n2 + 1 are requested
-      // ahead, the previous n2's sums are split while this one's MFMAs run
-      h8v ah[4], al[4];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { ah[i] = gfrag<h8v>(tb, lane16, T_A1 + 2 * i); al[i] = gfrag<h8v>(tb, lane16, T_A1 + 2 * i + 1); }
+    {
+      // ---- stage 1: per n2 three MFMAs (hi.hi + hi.lo + lo.hi); the signal words of n2 + 1 are requested ahead, the previous n2's sums
+      // are split while this one's MFMAs run
       auto xword = [&](int e, int n2) -> unsigned {
         const int m = 25 * e + n2;
         return m < 120 ? x0[m] : (m < 160 ? xm[m] : x0[m + 1]);
       };
-      unsigned d[2][8];
+      // n2 in pairs (2 m, 2 m + 1; 25 is padding): the two three-MFMA chains interleave; the signal words of the next pair are requested
+      // in front of this pair's MFMAs, the previous pair's sums are split behind them
+      constexpr int NP = (NN2 + 1) / 2;
+      unsigned d[2][2][8];
+      auto xload = [&](int buf, int m) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d[0][e] = xword(e, 0);
-      f32x4 c1[2];
-      static_for<0, NN2 + 1>([&](auto n2c) {
-        constexpr int n2 = decltype(n2c)::value;
-        if constexpr (n2 < NN2) {
-          if constexpr (n2 + 3 < NN2) { ah[(n2 + 3) & 3] = gfrag<h8v>(tb, lane16, T_A1 + 2 * (n2 + 3)); al[(n2 + 3) & 3] = gfrag<h8v>(tb, lane16, T_A1 + 2 * (n2 + 3) + 1); }
-          if constexpr (n2 + 1 < NN2) {
+        for (int e = 0; e < 8; ++e) {
+          d[buf][0][e] = xword(e, 2 * m);
+          d[buf][1][e] = 2 * m + 1 < NN2 ? xword(e, 2 * m + 1) : 0u;
+        }
+      };
+      xload(0, 0);
+      f32x4 c1[2][2];
+      static_for<0, NP + 1>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (m < NP && m % 2 == 0) chunk_sync((S_A1 / 2 + 2 * m) / 4);
+        if constexpr (m < NP) {
+          constexpr int ia = S_A1 / 2 + 2 * m, ib = (2 * m + 1 < NN2) ? ia + 1 : ia;
+          const h8v ah0 = *reinterpret_cast<const h8v*>(item(ia)), al0 = *reinterpret_cast<const h8v*>(item(ia) + 1024);
+          const h8v ah1 = *reinterpret_cast<const h8v*>(item(ib)), al1 = *reinterpret_cast<const h8v*>(item(ib) + 1024);
+          if constexpr (m + 1 < NP) xload((m + 1) & 1, m + 1);
+          const unsigned* d0 = d[m & 1][0];
+          const unsigned* d1 = d[m & 1][1];
+          const h8v xh0 = frag_of(__builtin_amdgcn_perm(d0[1], d0[0], 0x05040100u), __builtin_amdgcn_perm(d0[3], d0[2], 0x05040100u),
+                                  __builtin_amdgcn_perm(d0[5], d0[4], 0x05040100u), __builtin_amdgcn_perm(d0[7], d0[6], 0x05040100u));
+          const h8v xl0 = frag_of(__builtin_amdgcn_perm(d0[1], d0[0], 0x07060302u), __builtin_amdgcn_perm(d0[3], d0[2], 0x07060302u),
+                                  __builtin_amdgcn_perm(d0[5], d0[4], 0x07060302u), __builtin_amdgcn_perm(d0[7], d0[6], 0x07060302u));
+          const h8v xh1 = frag_of(__builtin_amdgcn_perm(d1[1], d1[0], 0x05040100u), __builtin_amdgcn_perm(d1[3], d1[2], 0x05040100u),
+                                  __builtin_amdgcn_perm(d1[5], d1[4], 0x05040100u), __builtin_amdgcn_perm(d1[7], d1[6], 0x05040100u));
+          const h8v xl1 = frag_of(__builtin_amdgcn_perm(d1[1], d1[0], 0x07060302u), __builtin_amdgcn_perm(d1[3], d1[2], 0x07060302u),
+                                  __builtin_amdgcn_perm(d1[5], d1[4], 0x07060302u), __builtin_amdgcn_perm(d1[7], d1[6], 0x07060302u));
+          f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+          z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh0, z0, 0, 0, 0);
+          z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh1, z1, 0, 0, 0);
+          z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xl0, z0, 0, 0, 0);
+          z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xl1, z1, 0, 0, 0);
+          c1[m & 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, xh0, z0, 0, 0, 0);
+          c1[m & 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, xh1, z1, 0, 0, 0);
+        }
+        if constexpr (m > 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d[(n2 + 1) & 1][e] = xword(e, n2 + 1);
+          for (int q = 0; q < 2; ++q) {
+            const int n2 = 2 * (m - 1) + q;
+            if (n2 < NN2) {
+              const f32x4& c = c1[(m - 1) & 1][q];
+              const float a0 = YSCALE * c[0], a1 = YSCALE * c[1], a2 = YSCALE * c[2], a3 = YSCALE * c[3];
+              const unsigned h01 = pk_rtz(a0, a1), h23 = pk_rtz(a2, a3);
+              yh01[n2] = h01;
+              yl01[n2] = pk_rtz(a0 - f16lo(h01), a1 - f16hi(h01));
+              yh23[n2] = h23;
+              yl23[n2] = pk_rtz(a2 - f16lo(h23), a3 - f16hi(h23));
+            }
           }
-          const unsigned* dd = d[n2 & 1];
-          const h8v xh = frag_of(__builtin_amdgcn_perm(dd[1], dd[0], 0x05040100u), __builtin_amdgcn_perm(dd[3], dd[2], 0x05040100u),
-                                 __builtin_amdgcn_perm(dd[5], dd[4], 0x05040100u), __builtin_amdgcn_perm(dd[7], dd[6], 0x05040100u));
-          const h8v xl = frag_of(__builtin_amdgcn_perm(dd[1], dd[0], 0x07060302u), __builtin_amdgcn_perm(dd[3], dd[2], 0x07060302u),
-                                 __builtin_amdgcn_perm(dd[5], dd[4], 0x07060302u), __builtin_amdgcn_perm(dd[7], dd[6], 0x07060302u));
-          f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[n2 & 3], xh, z, 0, 0, 0);
-          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[n2 & 3], xl, z, 0, 0, 0);
-          c1[n2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[n2 & 3], xh, z, 0, 0, 0);
         }
-        if constexpr (n2 > 0) {
-          const f32x4& c = c1[(n2 - 1) & 1];
-          const float a0 = YSCALE * c[0], a1 = YSCALE * c[1], a2 = YSCALE * c[2], a3 = YSCALE * c[3];
-          const unsigned h01 = pk_rtz(a0, a1), h23 = pk_rtz(a2, a3);
-          yh01[n2 - 1] = h01;
-          yl01[n2 - 1] = pk_rtz(a0 - f16lo(h01), a1 - f16hi(h01));
-          yh23[n2 - 1] = h23;
-          yl23[n2 - 1] = pk_rtz(a2 - f16lo(h23), a3 - f16hi(h23));
-        }
-        __builtin_amdgcn_sched_barrier(0);            // one n2 at a time: left alone, the scheduler pulls the reads of many steps forward and spills the sums
+        __builtin_amdgcn_sched_barrier(0);            // one pair at a time: left alone, the scheduler pulls the reads of many steps forward and spills the sums
       });
 #pragma unroll
       for (int i = NN2; i < 4 * NBLK; ++i) { yh01[i] = 0u; yl01[i] = 0u; yh23[i] = 0u; yl23[i] = 0u; }
     }
     U16_STAMP(4 + 4 * round);
-    // the log-mel rows of the first eight tiles overwrite signal words that only those tiles' stage 1 reads
-    if (round == 0) __syncthreads();
-    if (active) {
-      // ---- registers <-> lane groups: block m (n2 = 4 m + i in register i, pair g in lane group g) -> pair i in register i, n2 = 4 m + g in
-      // lane group g.  After it, element m of array P<kind>[i] is pair i's k-step data: P..[i][m] for m = 4 s .. 4 s + 3 = B fragment of step s
-      unsigned Ph01[4][NBLK], Pl01[4][NBLK], Ph23[4][NBLK], Pl23[4][NBLK];
+    // (the barrier of the next chunk also says: every wave is done with stage 1 -- the log-mel rows of the first eight tiles overwrite
+    // signal words that only those tiles' stage 1 reads)
+    chunk_sync(S_A2S / 8);
+    // ---- registers <-> lane groups: block m (n2 = 4 m + i in register i, pair g in lane group g) -> pair i in register i, n2 = 4 m + g in
+    // lane group g.  After it, element m of array P<kind>[i] is pair i's k-step data: P..[i][m] for m = 4 s .. 4 s + 3 = B fragment of step s
+    unsigned Ph01[4][NBLK], Pl01[4][NBLK], Ph23[4][NBLK], Pl23[4][NBLK];
+    unsigned pw1[NPROB][4], pw2[NPROB][4];
+    f32x4 c2s[4];
+    {
 #pragma unroll
       for (int m = 0; m < NBLK; ++m) {
         unsigned r[4];
@@ -359,44 +412,53 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
         for (int i = 0; i < 4; ++i) Pl23[i][m] = r[i];
       }
       U16_STAMP(5 + 4 * round);
-      // ---- stage 2: problem 2 i = components 0-1 of pair i, problem 2 i + 1 = components 2-3 (pair 3: the two reals, own matrix)
-      unsigned pw1[NPROB][4], pw2[NPROB][4];
+      // ---- stage 2: problem 2 i = components 0-1 of pair i, problem 2 i + 1 = components 2-3; the seven complex ones on the resident matrix
       const char* const a2l = a2s + lane16;
-      const gptr_t a2g = tb + (size_t)T_A2S * 1024;
+      auto resident = [&](int st) -> const char* { return a2l + (((st & 3) * 2 + (st >> 2)) * 2) * 1024; };
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        u16_problem<true>(a2l, a2g, lane16, Ph01[i], Pl01[i], pw1[2 * i], pw2[2 * i]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i < 3) u16_problem<true>(a2l, a2g, lane16, Ph23[i], Pl23[i], pw1[2 * i + 1], pw2[2 * i + 1]);
-        else u16_problem<false>(a2l, a2g, lane16, Ph23[i], Pl23[i], pw1[2 * i + 1], pw2[2 * i + 1]);
+      for (int pr = 0; pr < NPROB - 1; ++pr) {
+        f32x4 c2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pr & 1) u16_steps<0, 8>(resident, Ph23[pr >> 1], Pl23[pr >> 1], c2);
+        else u16_steps<0, 8>(resident, Ph01[pr >> 1], Pl01[pr >> 1], c2);
+        u16_powers(c2, pw1[pr], pw2[pr]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      U16_STAMP(6 + 4 * round);
-      // ---- mel: 5 row tiles x 8 problems, one K = 32 step each, split bf16 (W1 P1 + W1 P2 + W2 P1); weights streamed from L2, four fragment
-      // pairs ahead
-      f32x4 mel[MEL_TILES];
+      // the pair of reals: its own matrix, streamed (items S_A2S / 2 .. + 7 in step order (s, u))
 #pragma unroll
-      for (int t = 0; t < MEL_TILES; ++t) mel[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      constexpr int NW = MEL_TILES * NPROB;           // (t, problem) pairs in issue order: problem-major inside a tile
-      constexpr int AHEAD = 4;
-      bf8v w1[AHEAD], w2[AHEAD];
-      auto wfrag = [&](int it, int part) -> bf8v {
-        const int t = it / NPROB, pr = it % NPROB;
-        return gfrag<bf8v>(tb, lane16, T_MEL + (pr * MEL_TILES + t) * 2 + part);
-      };
+      for (int u = 0; u < 4; ++u) c2s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      u16_steps<0, 4>([&](int st) -> const char* { return item(S_A2S / 2 + st); }, Ph23[3], Pl23[3], c2s);
+    }
+    chunk_sync(S_A2S / 8 + 1);
+    {
+      u16_steps<4, 8>([&](int st) -> const char* { return item(S_A2S / 2 + st); }, Ph23[3], Pl23[3], c2s);
+      u16_powers(c2s, pw1[NPROB - 1], pw2[NPROB - 1]);
+    }
+    U16_STAMP(6 + 4 * round);
+    // ---- mel: 5 row tiles x 8 problems, one K = 32 step each, split bf16 (W1 P1 + W1 P2 + W2 P1); weights from the ring (items S_MEL / 2 + it)
+    f32x4 mel[MEL_TILES];
 #pragma unroll
-      for (int it = 0; it < AHEAD; ++it) { w1[it] = wfrag(it, 0); w2[it] = wfrag(it, 1); }
-      static_for<0, NW>([&](auto itc) {
-        constexpr int it = decltype(itc)::value;
-        constexpr int t = it / NPROB, pr = it % NPROB;
-        const bf8v a1 = w1[it % AHEAD], a2w = w2[it % AHEAD];
-        const bf8v b1 = __builtin_bit_cast(bf8v, (u32x4{pw1[pr][0], pw1[pr][1], pw1[pr][2], pw1[pr][3]}));
-        const bf8v b2 = __builtin_bit_cast(bf8v, (u32x4{pw2[pr][0], pw2[pr][1], pw2[pr][2], pw2[pr][3]}));
-        mel[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, mel[t], 0, 0, 0);
-        mel[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, mel[t], 0, 0, 0);
-        mel[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2w, b1, mel[t], 0, 0, 0);
-        if constexpr (it + AHEAD < NW) { w1[it % AHEAD] = wfrag(it + AHEAD, 0); w2[it % AHEAD] = wfrag(it + AHEAD, 1); }
-      });
+    for (int t = 0; t < MEL_TILES; ++t) mel[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for<0, MEL_TILES * NPROB / 2>([&](auto itc) {
+      // items (problem pr = it / 5, tile t = it % 5) two at a time: consecutive items feed different accumulators, their chains interleave
+      constexpr int it = 2 * decltype(itc)::value;
+      constexpr int t0 = it % MEL_TILES, pr0 = it / MEL_TILES, t1 = (it + 1) % MEL_TILES, pr1 = (it + 1) / MEL_TILES;
+      if constexpr (it % 4 == 0) chunk_sync(S_MEL / 8 + it / 4);
+      const bf8v a10 = *reinterpret_cast<const bf8v*>(item(S_MEL / 2 + it)), a20 = *reinterpret_cast<const bf8v*>(item(S_MEL / 2 + it) + 1024);
+      const bf8v a11 = *reinterpret_cast<const bf8v*>(item(S_MEL / 2 + it + 1)), a21 = *reinterpret_cast<const bf8v*>(item(S_MEL / 2 + it + 1) + 1024);
+      const bf8v b10 = __builtin_bit_cast(bf8v, (u32x4{pw1[pr0][0], pw1[pr0][1], pw1[pr0][2], pw1[pr0][3]}));
+      const bf8v b20 = __builtin_bit_cast(bf8v, (u32x4{pw2[pr0][0], pw2[pr0][1], pw2[pr0][2], pw2[pr0][3]}));
+      const bf8v b11 = __builtin_bit_cast(bf8v, (u32x4{pw1[pr1][0], pw1[pr1][1], pw1[pr1][2], pw1[pr1][3]}));
+      const bf8v b21 = __builtin_bit_cast(bf8v, (u32x4{pw2[pr1][0], pw2[pr1][1], pw2[pr1][2], pw2[pr1][3]}));
+      mel[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, b10, mel[t0], 0, 0, 0);
+      mel[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, b11, mel[t1], 0, 0, 0);
+      mel[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, b20, mel[t0], 0, 0, 0);
+      mel[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, b21, mel[t1], 0, 0, 0);
+      mel[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a20, b10, mel[t0], 0, 0, 0);
+      mel[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a21, b11, mel[t1], 0, 0, 0);
+    });
+    {
       // ---- log, utterance maximum, rows -> LDS (no branches: what does not exist goes to a spare word and counts as -inf)
       const bool ln = p.log_mode == SD_LOG_LN_EPS;
       const float lscale = ln ? 0.6931471805599453f : 3.0102999566398120f;      // v_log_f32 is log2
@@ -417,8 +479,8 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
         }
       vmax = sd_wave_max(vmax);
       if (lane == 0) scratch[round * 8 + wid] = vmax;
-      U16_STAMP(7 + 4 * round);
     }
+    U16_STAMP(7 + 4 * round);
   }
   __syncthreads();
   U16_STAMP(14);
@@ -488,7 +550,7 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
 
 size_t u16_lds_bytes(int n, int T) {
   const size_t words = (size_t)img_words(n) > (size_t)T * MELP ? (size_t)img_words(n) : (size_t)T * MELP;
-  return (size_t)A2_BYTES + SCRATCH_FLOATS * 4 + words * 4;
+  return (size_t)A2_BYTES + RING_BYTES + SCRATCH_FLOATS * 4 + words * 4;
 }
 
 unsigned short bf16_bits(float v) {
@@ -547,7 +609,7 @@ int sd_fbank_utt16_create_tables(sd_fbank_plan* plan, const float* window, const
           else if (r.kind == 2) v = w;
           else v = w * std::cos(ang - M_PI * (double)n2 / 25.0);
         }
-        put_f16(T_A1 + 2 * n2, T_A1 + 2 * n2 + 1, l, e, v);
+        put_f16(T_STREAM + S_A1 + 2 * n2, T_STREAM + S_A1 + 2 * n2 + 1, l, e, v);
       }
   // stage 2: fragment (u, s): rows 16 u + (l & 15): r = row & 3 = 2 q + out part, output idx = 2 (row >> 2 & 3) + q + 8 u;
   // k = 8 (l >> 4) + e: m' = e >> 1, in part = e & 1, n2 = 4 (4 s + m') + (l >> 4)
@@ -574,7 +636,8 @@ int sd_fbank_utt16_create_tables(sd_fbank_plan* plan, const float* window, const
                 if (yim == 1) v = oim == 0 ? std::cos(ph) : -std::sin(ph);
               }
             }
-            const size_t base = (special ? T_A2S : T_A2) + (size_t)(u * 2 + s) * 2;
+            // resident matrix: fragment pair (u, s) at index (u * 2 + s) * 2; the real pair's, streamed: in step order st = 4 s + u
+            const size_t base = special ? (size_t)T_STREAM + S_A2S + (size_t)(4 * s + u) * 2 : (size_t)T_A2 + (size_t)(u * 2 + s) * 2;
             put_f16(base, base + 1, l, e, A2SCALE * v);
           }
   // mel weights: problem pr = 2 i + (components 2-3 ? 1 : 0) of pair i; lane l holds row (mel) 16 t + (l & 15), k = 8 (l >> 4) + e:
@@ -596,7 +659,7 @@ int sd_fbank_utt16_create_tables(sd_fbank_plan* plan, const float* window, const
           float w = 0.f;
           if (bin >= 0 && bin < NFREQ && m < n_mels) w = (float)((double)mel_fb[(size_t)bin * n_mels + m] * PSCALE);
           const unsigned short w1 = bf16_bits(w);
-          const size_t f0 = T_MEL + (size_t)(pr * MEL_TILES + t) * 2;
+          const size_t f0 = (size_t)T_STREAM + S_MEL + (size_t)(pr * MEL_TILES + t) * 2;   // consumption order: problem-major
           tab[f0 * 512 + l * 8 + e] = w1;
           tab[(f0 + 1) * 512 + l * 8 + e] = bf16_bits(w - bf16_value(w1));
         }
