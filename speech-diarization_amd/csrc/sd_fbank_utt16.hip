@@ -275,7 +275,8 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
 
   const int ntiles = (p.T + FT - 1) / FT;
   const int j = lane & 15, g = lane >> 4;
-  const int hx = g & 1;                               // lane groups 2, 3 read what 0, 1 read: their half of the stage-1 matrix is zero
+  const int hx = g & 1;                               // lane groups 2, 3 read the samples 0, 1 read (and take their low halves)
+  const unsigned sel = g < 2 ? 0x05040100u : 0x07060302u;     // v_perm_b32 selector: the low (f16 hi) / high (f16 lo) 16 bits of two words
   // ---- the streamed tables.  Every wave of the workgroup needs the same fragments in the same order (stage-1 matrices, the real pair's
   // stage-2 matrix, the mel weights: 152 KB per tile round).  Read per wave from L2 they were the bottleneck of this kernel (8 waves x
   // 146 KB through the CU's 64 B/clk vector-memory path: ~18 k cycles per round, stamps); here they pass through a 16 KB LDS ring ONCE per
@@ -341,21 +342,17 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
           if constexpr (m + 1 < NP) xload((m + 1) & 1, m + 1);
           const unsigned* d0 = d[m & 1][0];
           const unsigned* d1 = d[m & 1][1];
-          const h8v xh0 = frag_of(__builtin_amdgcn_perm(d0[1], d0[0], 0x05040100u), __builtin_amdgcn_perm(d0[3], d0[2], 0x05040100u),
-                                  __builtin_amdgcn_perm(d0[5], d0[4], 0x05040100u), __builtin_amdgcn_perm(d0[7], d0[6], 0x05040100u));
-          const h8v xl0 = frag_of(__builtin_amdgcn_perm(d0[1], d0[0], 0x07060302u), __builtin_amdgcn_perm(d0[3], d0[2], 0x07060302u),
-                                  __builtin_amdgcn_perm(d0[5], d0[4], 0x07060302u), __builtin_amdgcn_perm(d0[7], d0[6], 0x07060302u));
-          const h8v xh1 = frag_of(__builtin_amdgcn_perm(d1[1], d1[0], 0x05040100u), __builtin_amdgcn_perm(d1[3], d1[2], 0x05040100u),
-                                  __builtin_amdgcn_perm(d1[5], d1[4], 0x05040100u), __builtin_amdgcn_perm(d1[7], d1[6], 0x05040100u));
-          const h8v xl1 = frag_of(__builtin_amdgcn_perm(d1[1], d1[0], 0x07060302u), __builtin_amdgcn_perm(d1[3], d1[2], 0x07060302u),
-                                  __builtin_amdgcn_perm(d1[5], d1[4], 0x07060302u), __builtin_amdgcn_perm(d1[7], d1[6], 0x07060302u));
+          // lane groups 0, 1 take the HIGH halves of their 8 samples, groups 2, 3 the LOW halves of the same samples (the selector is per lane):
+          // with the matrix fragments [A1h | A1h] and [A1l | 0] over k = 32, two MFMAs give A1h xh + A1h xl + A1l xh
+          const h8v xb0 = frag_of(__builtin_amdgcn_perm(d0[1], d0[0], sel), __builtin_amdgcn_perm(d0[3], d0[2], sel),
+                                  __builtin_amdgcn_perm(d0[5], d0[4], sel), __builtin_amdgcn_perm(d0[7], d0[6], sel));
+          const h8v xb1 = frag_of(__builtin_amdgcn_perm(d1[1], d1[0], sel), __builtin_amdgcn_perm(d1[3], d1[2], sel),
+                                  __builtin_amdgcn_perm(d1[5], d1[4], sel), __builtin_amdgcn_perm(d1[7], d1[6], sel));
           f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-          z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh0, z0, 0, 0, 0);
-          z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh1, z1, 0, 0, 0);
-          z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xl0, z0, 0, 0, 0);
-          z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xl1, z1, 0, 0, 0);
-          c1[m & 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, xh0, z0, 0, 0, 0);
-          c1[m & 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, xh1, z1, 0, 0, 0);
+          z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xb0, z0, 0, 0, 0);
+          z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xb1, z1, 0, 0, 0);
+          c1[m & 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, xb0, z0, 0, 0, 0);
+          c1[m & 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, xb1, z1, 0, 0, 0);
         }
         if constexpr (m > 0) {
 #pragma unroll
@@ -593,23 +590,27 @@ int sd_fbank_utt16_create_tables(sd_fbank_plan* plan, const float* window, const
     tab[frag_hi * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, hi);
     tab[frag_lo * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, lo);
   };
-  // stage 1: A operand of v_mfma_f32_16x16x32_f16: lane l holds row l & 15, k = 8 (l >> 4) + e = n1 (k >= 16: zero)
+  // stage 1: A operand of v_mfma_f32_16x16x32_f16: lane l holds row l & 15, k = 8 (l >> 4) + e.  The B operand carries the HIGH halves of the
+  // samples n1 = k in k < 16 and their LOW halves in k >= 16 (n1 = k - 16), so fragment 0 = [A1h | A1h] and fragment 1 = [A1l | 0]:
+  // two MFMAs = A1h xh + A1h xl + A1l xh
   for (int n2 = 0; n2 < NN2; ++n2)
     for (int l = 0; l < 64; ++l)
       for (int e = 0; e < 8; ++e) {
-        const int rho = l & 15, k = 8 * (l >> 4) + e;
-        double v = 0.0;
-        if (k < 16) {
-          const int n = 25 * k + n2;
-          const RowOf r = row_of(rho >> 2, rho & 3);
-          const double ang = 2.0 * M_PI * (double)(((long)r.k1 * n) % NFFT) / (double)NFFT;
-          const double w = A1SCALE * (double)window[n];
-          if (r.kind == 0) v = w * std::cos(ang);
-          else if (r.kind == 1) v = -w * std::sin(ang);
-          else if (r.kind == 2) v = w;
-          else v = w * std::cos(ang - M_PI * (double)n2 / 25.0);
-        }
-        put_f16(T_STREAM + S_A1 + 2 * n2, T_STREAM + S_A1 + 2 * n2 + 1, l, e, v);
+        const int rho = l & 15, k = 8 * (l >> 4) + e, n1 = k & 15;
+        const int n = 25 * n1 + n2;
+        const RowOf r = row_of(rho >> 2, rho & 3);
+        const double ang = 2.0 * M_PI * (double)(((long)r.k1 * n) % NFFT) / (double)NFFT;
+        const double w = A1SCALE * (double)window[n];
+        double v;
+        if (r.kind == 0) v = w * std::cos(ang);
+        else if (r.kind == 1) v = -w * std::sin(ang);
+        else if (r.kind == 2) v = w;
+        else v = w * std::cos(ang - M_PI * (double)n2 / 25.0);
+        const _Float16 hi = (_Float16)(float)v;
+        const _Float16 lo = (_Float16)(float)(v - (double)(float)hi);
+        const size_t f0 = (size_t)T_STREAM + S_A1 + 2 * n2;
+        tab[f0 * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, hi);
+        tab[(f0 + 1) * 512 + l * 8 + e] = k < 16 ? __builtin_bit_cast(unsigned short, lo) : (unsigned short)0;
       }
   // stage 2: fragment (u, s): rows 16 u + (l & 15): r = row & 3 = 2 q + out part, output idx = 2 (row >> 2 & 3) + q + 8 u;
   // k = 8 (l >> 4) + e: m' = e >> 1, in part = e & 1, n2 = 4 (4 s + m') + (l >> 4)
