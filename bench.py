@@ -401,9 +401,9 @@ def main():
                 "traffic": traffic.get(other_kernel), "traffic_source": "file profiles/traffic.json; NOT measured in this run",
             },
             "roofline_fbank": {
-                "kernel": "fbank_utt_kernel (ONE launch per batch: waveform -> log-mel incl. the utterance-level top_db floor and mean removal)", "bound": "hbm",
+                "kernel": "fbank_utt16_kernel (ONE launch per batch: waveform -> log-mel incl. the utterance-level top_db floor and mean removal)", "bound": "hbm",
                 "achieved": fb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb_gbs / HBM_PEAK_GBS,
-                "traffic": traffic.get("fbank_utt_kernel"),
+                "traffic": traffic.get("fbank_utt16_kernel"),
                 "traffic_source": "file profiles/traffic.json; NOT measured in this run",
                 "launches": fb_n, "avg_launch_ms": fb_ms / max(fb_n, 1),
                 "bytes_per_launch": fb_bytes / max(fb_n, 1),

@@ -36,7 +36,7 @@
 //     distinct bank slots (41 j mod 16 = 9 j).
 // Measured (MI355X, rocprofv3, 10 000 segments of 2 s per launch): 2.32 ms main kernel + 0.45 ms finalize (round 1: 6.0 + 0.42),
 // 830 GB/s of the 192 320 algorithmic bytes per segment for the main kernel alone, 695 GB/s with the finalize pass.  Since round 4
-// utterances of up to 216 frames take the one-launch kernel of sd_fbank_utt.hip (2.10 ms for the same work); this kernel serves
+// utterances of up to 32 100 samples (201 frames) take the one-launch kernel of sd_fbank_utt16.hip (1.6 ms for the same work); this kernel serves
 // the longer ones.  Two things found on the way (both hipcc codegen, both worth ~1 ms per 5000 segments):
 // a multiply placed next to the staging loads made every load wait on its own (79 `s_waitcnt vmcnt(0)`), and predicated
 // loads become branches with a wait each; the staging loop therefore loads unconditionally from a clamped index and
@@ -509,7 +509,7 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
                 m16[o] = part == 0 ? w1 : bf16_bits(w - bf16_value(w1));
               }
   }
-  sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr, nullptr};
   hipError_t e1 = hipMalloc(&plan->basis16_dev, V2_BASIS_BYTES);
   hipError_t e2 = e1 == hipSuccess ? hipMalloc(&plan->melw16_dev, V2_MELW_BYTES) : e1;
   if (e1 == hipSuccess && e2 == hipSuccess) {
@@ -524,8 +524,7 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
     delete plan;
     return nullptr;
   }
-  if (sd_fbank_utt_create_tables(plan, window, mel_fb) != SD_OK || sd_fbank_utt16_create_tables(plan, window, mel_fb) != SD_OK) {      // tables of the one-launch kernels
-    sd_fbank_utt_destroy_tables(plan);
+  if (sd_fbank_utt16_create_tables(plan, window, mel_fb) != SD_OK) {      // tables of the one-launch kernel (sd_fbank_utt16.hip)
     (void)hipFree(plan->basis16_dev);
     (void)hipFree(plan->melw16_dev);
     delete plan;
@@ -538,7 +537,6 @@ extern "C" void sd_fbank_plan_destroy(sd_fbank_plan* plan) {
   if (!plan) return;
   (void)hipFree(plan->basis16_dev);
   (void)hipFree(plan->melw16_dev);
-  sd_fbank_utt_destroy_tables(plan);
   sd_fbank_utt16_destroy_tables(plan);
   delete plan;
 }
@@ -584,11 +582,9 @@ static int fbank_launch(const sd_fbank_plan* plan, const float* wav_dev, long lo
     SD_CHECK_ARG(n >= 1, "sd_fbank_f32: empty waveform");
   SD_CHECK_ARG(ws_dev != nullptr && ws_bytes >= sd_fbank_workspace_bytes(plan, B, n),
                "sd_fbank_f32: workspace too small (%zu < %zu)", ws_bytes, sd_fbank_workspace_bytes(plan, B, n));
-  // utterances whose padded signal fits the CU's LDS: ONE launch, one workgroup per utterance (sd_fbank_utt.hip)
+  // utterances whose padded signal fits the CU's LDS: ONE launch, one workgroup per utterance (sd_fbank_utt16.hip)
   if (n_total >= 4 && sd_fbank_utt16_supported(plan, n))    // (16-byte loads: four samples behind `wav`)
     return sd_fbank_utt16_launch(plan, wav_dev, n_total, starts_dev, B, n, mean_norm, out_dev, ld_out, stream);
-  if (n_total >= 4 && sd_fbank_utt_supported(plan, n))
-    return sd_fbank_utt_launch(plan, wav_dev, n_total, starts_dev, B, n, mean_norm, out_dev, ld_out, stream);
   const int T = 1 + n / HOP;
   Fbank2Args a;
   a.wav = wav_dev; a.B = B; a.n = n; a.T = T;

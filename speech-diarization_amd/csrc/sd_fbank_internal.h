@@ -1,4 +1,4 @@
-// Shared between sd_fbank.hip (plan, tables of the folded-DFT kernel, dispatch) and sd_fbank_utt.hip (the one-launch,
+// Shared between sd_fbank.hip (plan, tables of the folded-DFT kernel, dispatch) and sd_fbank_utt16.hip (the one-launch,
 // one-workgroup-per-utterance kernel with the factored DFT).
 #pragma once
 #include "sd_common.h"
@@ -8,21 +8,11 @@ struct sd_fbank_plan {
   float log_eps, top_db;
   void* basis16_dev;       // folded-DFT kernel: f16 [pass][k step][tile][Chi | Clo | Shi | Slo][64][8]
   void* melw16_dev;        // folded-DFT kernel: bf16 [bin tile][k half][mel tile][W1 | W2][64][8]
-  void* utt_a1_dev;        // factored kernel, stage 1: f16 [25 n2][hi | lo][64 lanes][8]
-  void* utt_a2_dev;        // factored kernel, stage 2: f16 [2 row tiles][4 k steps][hi | lo][64 lanes][8]
-  void* utt_melw_dev;      // factored kernel, mel: bf16 [9 problems][2 row tiles][3 mel tiles][W1 | W2][64 lanes][8]
-  void* utt16_tables_dev;  // 16-frame-tile factored kernel (sd_fbank_utt16.hip): all of its fragment tables, 1 KB each
+  void* utt16_tables_dev;  // factored one-launch kernel (sd_fbank_utt16.hip): all of its fragment tables, 1 KB each
 };
 
-// device tables of the factored kernel from the window (n_fft values) and the mel filterbank [n_fft / 2 + 1][n_mels]
-int sd_fbank_utt_create_tables(sd_fbank_plan* plan, const float* window, const float* mel_fb);
-void sd_fbank_utt_destroy_tables(sd_fbank_plan* plan);
-// frames per utterance the factored kernel takes (the utterance's padded signal must fit the CU's LDS)
-bool sd_fbank_utt_supported(const sd_fbank_plan* plan, int n);
-int sd_fbank_utt_launch(const sd_fbank_plan* plan, const float* wav_dev, long long n_total, const long long* starts_dev, int B, int n,
-                        int mean_norm, float* out_dev, int ld_out, hipStream_t stream);
-
-// the same with 16-frame tiles and two waves per SIMD (sd_fbank_utt16.hip): utterances of up to 208 frames
+// device tables of the factored kernel from the window (n_fft values) and the mel filterbank [n_fft / 2 + 1][n_mels]; utterances of up to
+// 32 100 samples = 201 frames (the padded signal must fit the CU's LDS beside the table ring)
 int sd_fbank_utt16_create_tables(sd_fbank_plan* plan, const float* window, const float* mel_fb);
 void sd_fbank_utt16_destroy_tables(sd_fbank_plan* plan);
 bool sd_fbank_utt16_supported(const sd_fbank_plan* plan, int n);

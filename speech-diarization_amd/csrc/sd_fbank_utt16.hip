@@ -1,24 +1,42 @@
-// Log-mel filterbank in ONE launch, 16-frame tiles: the form of sd_fbank_utt.hip that runs TWO waves per SIMD.
+// Log-mel filterbank in ONE launch: one workgroup per utterance, factored DFT on the f16 matrix cores, floor + mean removal in LDS.
 //
-// sd_fbank_utt.hip (32-frame tiles on 32x32x16 MFMAs) keeps a frame's stage-1 sums on two lanes: 250 registers per lane, one
-// wave per SIMD, two passes over stage 1, and ends up bound by instruction issue (~6 cycles per instruction for a wave that
-// is alone on its SIMD, matrix pipe 23 % busy).  Here a tile is 16 frames on v_mfma_f32_16x16x32_f16: a frame's state lies on FOUR
-// lanes (lane group g = lane >> 4 holds accumulator rows 4 g .. 4 g + 3), accumulators are 4 registers instead of 16, and the
-// whole per-lane state fits 256 registers: eight waves per workgroup, two per SIMD, one pass, half the instructions per frame.
+// Same arithmetic contract as sd_fbank.hip (torchaudio MelSpectrogram + log + mean removal [REF speech_encode.py:17-36], or the
+// speechbrain Fbank + sentence mean-norm front end of EncoderClassifier.encode_batch [REF speech_encode.py:77]; SURVEY.md Appendix
+// A.1 / A.2); what changes is the shape of the work.  The folded-DFT kernel there streams a 364 KB basis through LDS for every 128
+// frames (one L2 -> LDS round trip and one barrier per k step: matrix pipe 25 % busy) and needs a second launch for the
+// utterance-level top_db floor and the mean over T, which re-reads and re-writes the whole output.  Here:
 //
-// Arithmetic (same contract and same scales as sd_fbank_utt.hip; [REF speech_encode.py:17-36, 77]):
-//   400 = 16 x 25, n = 25 n1 + n2.  Stage 1, per n2: Y[k1, n2] = sum_{n1 < 16} w[n] x[n] e^{-2 pi i k1 n / 400}.  x is real, so
-//   Y[16 - k1, n2] = e^{-2 pi i n2 / 25} conj Y[k1, n2]: k1 = 1..7 are complex, Y[0, n2] is real and Y[8, n2] e^{+i pi n2 / 25} =: rho[n2]
-//   is real: SIXTEEN real rows per n2 = one 16-row MFMA (K = 32 with the upper half of the matrix zero).  Rows by lane group:
-//   g = 0: k1 = 1, 2; g = 1: k1 = 3, 4; g = 2: k1 = 5, 6; g = 3: k1 = 7 and the two reals (Y[0], rho): a "pair" of problems per group.
-//   Stage 2, per problem: a 25-point DFT over n2.  Its contraction index n2 lives in separate registers of ONE lane group; a 4 x 4
-//   transpose between four registers (n2 = 4 m .. 4 m + 3) and the four lane groups (v_permlane16_swap + v_permlane32_swap, in
-//   place) turns that into "register = pair, lane group g = n2 mod 4", i.e. the B fragment of a K = 32 step: k = 8 g + 2 m' + part
-//   <-> n2 = 4 (4 s + m') + g.  Complex problems share one 64 x 64 matrix (outputs idx 0..12 are bins k1 + 16 idx, idx 13..24 the
-//   conjugates of bins 16 - k1 + 16 (24 - idx)); the pair of reals has its own (rows 0..12: bins 16 k2, rows 13..25: bins 8 + 16 k2
-//   with the phase e^{-i pi n2 / 25} folded in).  A lane then holds re / im of two outputs per 16-row tile: eight powers per problem
-//   = the B fragment of ONE K = 32 step of the mel product (80 mels = five 16-row tiles, split bf16 as before).
-// Per 16-frame tile: 75 + 192 + 120 MFMAs of 16 cycles (sd_fbank_utt.hip per 16 frames: 264 of 32).
+//  * One 512-thread workgroup owns one utterance of up to 32 100 samples (201 frames: the padded signal must fit the CU's 160 KB of LDS
+//    beside the resident matrix and the table ring; longer utterances run on sd_fbank.hip's two launches).  Its padded signal (n + 400 samples) is staged ONCE into LDS,
+//    clamped to +-16, scaled by the power of two 2^k that puts the UTTERANCE's peak into [2^13, 2^14) and split into two f16 halves per
+//    sample (hi = f16(v), lo = f16(v - hi): one dword), at word i + i / 160 (frame stride 161 words: the 16 frames of a wave tile fall on
+//    16 distinct banks).  The log-mel rows of the whole utterance are collected in LDS too (over the dead signal), so the utterance
+//    maximum, the top_db floor and the mean over T are applied before the ONLY write of the output: algorithmic traffic (128 000 B read +
+//    64 320 B written per 2 s segment), no atomics, no second pass.
+//  * 400 = 16 x 25, n = 25 n1 + n2.  Stage 1, per n2: Y[k1, n2] = sum_{n1 < 16} w[n] x[n] e^{-2 pi i k1 n / 400} (window and twiddles folded
+//    into one matrix per n2).  x is real, so Y[16 - k1, n2] = e^{-2 pi i n2 / 25} conj Y[k1, n2]: k1 = 1..7 are complex, Y[0, n2] is real and
+//    Y[8, n2] e^{+i pi n2 / 25} =: rho[n2] is real: SIXTEEN real rows per n2 = the 16 rows of one v_mfma_f32_16x16x32_f16.  Its K = 32 carries
+//    the HIGH halves of the 16 samples in k < 16 and their LOW halves in k >= 16 (lane groups 0, 1 / 2, 3 of the B operand, one v_perm
+//    selector per lane), against [A1h | A1h] and [A1l | 0]: two MFMAs = A1h xh + A1h xl + A1l xh, f32-level accuracy (2^-21 per stage).
+//    Rows by lane group g = lane >> 4 (a lane holds accumulator rows 4 g .. 4 g + 3 of its frame): g = 0: k1 = 1, 2; g = 1: k1 = 3, 4;
+//    g = 2: k1 = 5, 6; g = 3: k1 = 7 and the two reals (Y[0], rho): a "pair" of problems per group, 100 packed registers per lane for
+//    the split sums of all 25 n2 -- which is what lets TWO waves share a SIMD (a first version with 32-frame tiles on 32x32x16 MFMAs
+//    kept a frame's sums on two lanes, 250 registers: one wave per SIMD, two passes over stage 1, ~6 cycles per instruction, 2.10 ms
+//    per 10 000 segments against 1.6 here).
+//  * Stage 2, per problem: a 25-point DFT over n2.  Its contraction index n2 lives in separate registers of ONE lane group; a 4 x 4
+//    transpose between four registers (n2 = 4 m .. 4 m + 3) and the four lane groups (v_permlane16_swap + v_permlane32_swap, in place)
+//    turns that into "register = pair, lane group g = n2 mod 4", i.e. the B fragment of a K = 32 step: k = 8 g + 2 m' + part <-> n2 =
+//    4 (4 s + m') + g.  Complex problems share one 64 x 64 matrix, LDS resident (outputs idx 0..12 are bins k1 + 16 idx, idx 13..24 the
+//    conjugates of bins 16 - k1 + 16 (24 - idx)); the pair of reals has its own (rows 0..12: bins 16 k2, rows 13..25: bins 8 + 16 k2 with
+//    the phase e^{-i pi n2 / 25} folded in).  The stage-1 sums are split hi + lo again (scaled by 2^-8 first: < 2^15), three MFMAs per step.
+//  * A lane then holds re / im of two outputs per 16-row tile: eight powers per problem = the B fragment of ONE K = 32 step of the mel
+//    product (80 mels = five 16-row tiles; power spectrum as split bf16 against split bf16 weights, 2^-16).
+//  * The f16 MFMA flushes subnormal operands, so every LOW half that matters must be a normal number (>= 2^-14) and every value < 2^16:
+//    hence the per-utterance 2^k (low halves normal down to 100 dB below the utterance's peak, at every signal level), both matrices
+//    x 2^5, the 2^-8 on the stage-1 sums; the mel weights and one multiply in front of the log take 2^(-2 (k + 2)) back.
+//  * The tables every wave needs in the same order (stage-1 matrices 50 KB, the real pair's matrix 16 KB, mel weights 80 KB per tile
+//    round) pass through a 16 KB LDS ring once per round (see the kernel): read per wave from L2 they were the bottleneck.
+// Per 16-frame tile: 50 + 192 + 120 MFMAs of 16 cycles.  Measured: DESIGN.md section 4.
 #include "sd_fbank_internal.h"
 #include <cmath>
 #include <cstring>
@@ -113,7 +131,7 @@ __device__ __forceinline__ h8v frag_of(unsigned a, unsigned b, unsigned c, unsig
   return __builtin_bit_cast(h8v, v);
 }
 template <typename V>
-__device__ __forceinline__ V gfrag(gptr_t base, unsigned lane16, int frag) {      // uniform base + 32-bit lane offset (see sd_fbank_utt.hip)
+__device__ __forceinline__ V gfrag(gptr_t base, unsigned lane16, int frag) {      // uniform base + 32-bit lane offset: the base stays in scalar registers
   return *reinterpret_cast<const __attribute__((address_space(1))) V*>(base + (size_t)frag * 1024 + lane16);
 }
 
@@ -184,8 +202,10 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
         *reinterpret_cast<const u32x4*>(p.tables + (size_t)T_A2 * 1024 + (i * U16_THREADS + tid) * 16);
   if (tid < 16) scratch[tid] = -INFINITY;
 
-  // ---- the padded signal -> LDS, exactly as in sd_fbank_utt.hip (clamped, scaled by the utterance's 2^k, split into two f16 halves,
-  // word i + i / 160), with 512 threads
+  // ---- the padded signal -> LDS (clamped, scaled by the utterance's 2^k, split into two f16 halves, word i + i / 160).  A thread owns groups
+  // of four consecutive samples inside the utterance and the signal (16-byte loads, all in flight at once, kept in registers across the peak
+  // reduction so that the image is written once); the padding at both ends -- and whatever hangs over an end of the signal when a window
+  // does -- goes element by element through a small loop (raw value to LDS, scaled in place after the reduction)
   const int L = p.n + NFFT;
   {
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -680,8 +700,8 @@ void sd_fbank_utt16_destroy_tables(sd_fbank_plan* plan) {
 }
 
 bool sd_fbank_utt16_supported(const sd_fbank_plan* plan, int n) {
-  static const int which = [] { const char* e = sd_experiment_env("SD_FBANK_UTT"); return e ? atoi(e) : 16; }();   // A/B: 0 folded kernel, 32 the 32-frame-tile kernel
-  if (which != 16 || !plan->utt16_tables_dev) return false;
+  static const bool on = [] { const char* e = sd_experiment_env("SD_FBANK_UTT"); return !(e && atoi(e) == 0); }();   // A/B: SD_FBANK_UTT=0 sends every length to the folded kernel
+  if (!on || !plan->utt16_tables_dev) return false;
   const int T = 1 + n / HOP;
   return T <= U16_MAX_T && u16_lds_bytes(n, T) <= (size_t)LDS_LIMIT;
 }
