@@ -309,8 +309,15 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
                                      (__attribute__((address_space(3))) void*)(ring + ((q & 1) * 8 + wid) * 1024), 16, 0, 0);
   };
   auto chunk_sync = [&](int q) {                      // in front of the first use of chunk q
+#ifdef SD_U16_DIAG_NOWAIT      // timing-only diagnostic build (results wrong): what the wait for the chunk's own DMA costs
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#elif defined(SD_U16_DIAG_NOBARRIER)   // timing-only diagnostic build (results wrong): what the lock step costs
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
     if (q + 1 < NCHUNK) dma(q + 1);
   };
   // LDS address (+ 16 lane) of stream-relative item i (= fragments 2 i, 2 i + 1) of the current round
