@@ -181,6 +181,40 @@ __device__ __forceinline__ void u16_steps(AddrOf&& addr_of, const unsigned (&yh)
   }
 }
 
+// the same for TWO problems that share the matrix (all complex problems do): each fragment pair is read from LDS once and feeds both
+template <typename AddrOf>
+__device__ __forceinline__ void u16_steps2(AddrOf&& addr_of, const unsigned (&yhA)[NBLK], const unsigned (&ylA)[NBLK], const unsigned (&yhB)[NBLK],
+                                           const unsigned (&ylB)[NBLK], f32x4 (&ca)[4], f32x4 (&cb)[4]) {
+  h8v ah0 = *reinterpret_cast<const h8v*>(addr_of(0)), al0 = *reinterpret_cast<const h8v*>(addr_of(0) + 1024);
+  h8v ah1 = *reinterpret_cast<const h8v*>(addr_of(1)), al1 = *reinterpret_cast<const h8v*>(addr_of(1) + 1024);
+#pragma unroll
+  for (int st = 0; st < 8; st += 2) {
+    const int s = st >> 2, u = st & 3;
+    const h8v bhA = frag_of(yhA[4 * s], yhA[4 * s + 1], yhA[4 * s + 2], s == 0 ? yhA[3] : 0u);
+    const h8v blA = frag_of(ylA[4 * s], ylA[4 * s + 1], ylA[4 * s + 2], s == 0 ? ylA[3] : 0u);
+    const h8v bhB = frag_of(yhB[4 * s], yhB[4 * s + 1], yhB[4 * s + 2], s == 0 ? yhB[3] : 0u);
+    const h8v blB = frag_of(ylB[4 * s], ylB[4 * s + 1], ylB[4 * s + 2], s == 0 ? ylB[3] : 0u);
+    h8v nh0 = ah0, nl0 = al0, nh1 = ah1, nl1 = al1;
+    if (st + 2 < 8) {
+      nh0 = *reinterpret_cast<const h8v*>(addr_of(st + 2)); nl0 = *reinterpret_cast<const h8v*>(addr_of(st + 2) + 1024);
+      nh1 = *reinterpret_cast<const h8v*>(addr_of(st + 3)); nl1 = *reinterpret_cast<const h8v*>(addr_of(st + 3) + 1024);
+    }
+    ca[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhA, ca[u], 0, 0, 0);
+    cb[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhB, cb[u], 0, 0, 0);
+    ca[u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhA, ca[u + 1], 0, 0, 0);
+    cb[u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhB, cb[u + 1], 0, 0, 0);
+    ca[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blA, ca[u], 0, 0, 0);
+    cb[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blB, cb[u], 0, 0, 0);
+    ca[u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blA, ca[u + 1], 0, 0, 0);
+    cb[u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blB, cb[u + 1], 0, 0, 0);
+    ca[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhA, ca[u], 0, 0, 0);
+    cb[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhB, cb[u], 0, 0, 0);
+    ca[u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhA, ca[u + 1], 0, 0, 0);
+    cb[u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhB, cb[u + 1], 0, 0, 0);
+    ah0 = nh0; al0 = nl0; ah1 = nh1; al1 = nl1;
+  }
+}
+
 __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   char* const a2s = smem_raw;                                                        // stage-2 matrix fragments (16 KB); later the column sums
@@ -439,14 +473,23 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
       // ---- stage 2: problem 2 i = components 0-1 of pair i, problem 2 i + 1 = components 2-3; the seven complex ones on the resident matrix
       const char* const a2l = a2s + lane16;
       auto resident = [&](int st) -> const char* { return a2l + (((st & 3) * 2 + (st >> 2)) * 2) * 1024; };
+      // (two problems at a time against each fragment pair: problems 2 i, 2 i + 1 = the two of pair i; problem 6 alone)
 #pragma unroll
-      for (int pr = 0; pr < NPROB - 1; ++pr) {
+      for (int i = 0; i < 3; ++i) {
+        f32x4 ca[4], cb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ca[u] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        u16_steps2(resident, Ph01[i], Pl01[i], Ph23[i], Pl23[i], ca, cb);
+        u16_powers(ca, pw1[2 * i], pw2[2 * i]);
+        u16_powers(cb, pw1[2 * i + 1], pw2[2 * i + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
         f32x4 c2[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) c2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (pr & 1) u16_steps<0, 8>(resident, Ph23[pr >> 1], Pl23[pr >> 1], c2);
-        else u16_steps<0, 8>(resident, Ph01[pr >> 1], Pl01[pr >> 1], c2);
-        u16_powers(c2, pw1[pr], pw2[pr]);
+        u16_steps<0, 8>(resident, Ph01[3], Pl01[3], c2);
+        u16_powers(c2, pw1[6], pw2[6]);
         __builtin_amdgcn_sched_barrier(0);
       }
       // the pair of reals: its own matrix, streamed (items S_A2S / 2 .. + 7 in step order (s, u))
