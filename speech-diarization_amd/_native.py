@@ -21,6 +21,7 @@ SD_DT_F32, SD_DT_F16, SD_DT_SPLIT16 = 0, 1, 2
 SD_TUNE_SKINNY_TILES = 1
 SD_TUNE_WIDE_TILES = 2
 SD_TUNE_F16_NARROW_TILES = 3
+SD_TUNE_S64_TILES = 4
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
 SD_ABI_VERSION = 8

@@ -48,21 +48,26 @@ __device__ unsigned long long sd_c32_stamp_buf[8192 * 10];
 // padding (a wave instruction lands 8 rows = 1 KB contiguously), so the 16-byte chunk a lane FETCHES is
 // permuted at the source, chunk c of row r living at position c ^ ((r >> 1) & 7): the fragment reads of 16
 // consecutive rows then hit 16 different bank groups.
-template <bool DMA>
+// NJ: 32-column MFMA tiles per wave: 2 = the 128x128 tile; 1 = a 128x64 tile (DMA only; conv_gemm_f32_n64_kernel below)
+template <bool DMA, int NJ = 2>
 __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int vec, const int tile_m, const int tile_n, float* smem,
                                               const bool mirror = false) {
+  static_assert(NJ == 2 || (NJ == 1 && DMA), "the half-width tile exists in the LDS-DMA form only");
+  constexpr int TBN = 64 * NJ;                // tile columns
+  constexpr int TLDC = TBN + 4;               // padded row of the C tile
+  constexpr int NBI = TBN / 32;               // staging instructions per wave for the weight rows
 #ifdef SD_STAMP
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
   constexpr int LDS_ROW = DMA ? BK : LDP;     // floats per staged row
   float* As = smem;                           // [2][BM][LDS_ROW]
-  float* Bs = smem + 2 * BM * LDS_ROW;        // [2][BN][LDS_ROW]
+  float* Bs = smem + 2 * BM * LDS_ROW;        // [2][TBN][LDS_ROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BM, n0 = tile_n * TBN;
 
   // staging role: 8 threads per 32-float row, 4 rows per thread.  Rows past M and output
   // channels past cout are clamped to the last valid one (their results are never stored)
@@ -142,18 +147,20 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
       SD_GLDS16_F32(aptr[i] + acol, As + buf * BM * BK + (32 * i + 8 * wid) * BK);
-      SD_GLDS16_F32(wptr[i] + gchunk, Bs + buf * BN * BK + (32 * i + 8 * wid) * BK);
-      wptr[i] += BK;
+      if (i < NBI) {
+        SD_GLDS16_F32(wptr[i] + gchunk, Bs + buf * TBN * BK + (32 * i + 8 * wid) * BK);
+        wptr[i] += BK;
+      }
     }
     if (i1 == 4) advance();
   };
   auto gdma = [&](int buf) { gdma_part(buf, 0, 4); };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -171,16 +178,16 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
     f.a0 = *reinterpret_cast<const f32x4*>(a + o);
     f.a1 = *reinterpret_cast<const f32x4*>(a + 32 * LDS_ROW + o);
     f.b0 = *reinterpret_cast<const f32x4*>(b + o);
-    f.b1 = *reinterpret_cast<const f32x4*>(b + 32 * LDS_ROW + o);
+    if (NJ == 2) f.b1 = *reinterpret_cast<const f32x4*>(b + 32 * LDS_ROW + o);
     return f;
   };
   auto mma = [&](const Frag& f) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[r], f.b0[r], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[r], f.b1[r], acc[0][1], 0, 0, 0);
+      if (NJ == 2) acc[0][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[r], f.b1[r], acc[0][NJ - 1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[r], f.b0[r], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[r], f.b1[r], acc[1][1], 0, 0, 0);
+      if (NJ == 2) acc[1][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[r], f.b1[r], acc[1][NJ - 1], 0, 0, 0);
     }
   };
 
@@ -209,7 +216,7 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     const float* a = As + cur * BM * LDS_ROW + (wm * 64 + frag_row) * LDS_ROW + (DMA ? 0 : frag_k);
-    const float* b = Bs + cur * BN * LDS_ROW + (wn * 64 + frag_row) * LDS_ROW + (DMA ? 0 : frag_k);
+    const float* b = Bs + cur * TBN * LDS_ROW + (wn * 32 * NJ + frag_row) * LDS_ROW + (DMA ? 0 : frag_k);
     // DMA pieces go out in two halves, behind the first and the second MFMA group (measured on 1024x1024:
     // all at the start of the step 133.8, all behind group 1 133.3, halves 134.7, quarters 129.8 TFLOP/s)
     Frag f0 = fread(a, b, 0);
@@ -249,14 +256,14 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
   float* Cs = smem;
   const int hrow = (lane >> 5) * 4;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int cl = wn * 64 + ni * 32 + (lane & 31);
+  for (int ni = 0; ni < NJ; ++ni) {
+    const int cl = wn * 32 * NJ + ni * 32 + (lane & 31);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-        Cs[rl * LDC + cl] = acc[mi][ni][r];
+        Cs[rl * TLDC + cl] = acc[mi][ni][r];
       }
     }
   }
@@ -268,8 +275,8 @@ __device__ __forceinline__ void conv_tile_f32(const sd_conv_args& p, const int v
 #ifdef SD_STAMP
   const unsigned long long t_e2 = __builtin_amdgcn_s_memtime();
 #endif
-  sd_store_tile<float, BM, BN, 256>(p, Cs, LDC, m0, n0, tid, vec);
-  if (mirror && tile_m != tile_n) {
+  sd_store_tile<float, BM, TBN, 256, 2, NJ == 2 ? 3 : 2>(p, Cs, TLDC, m0, n0, tid, vec);
+  if (NJ == 2 && mirror && tile_m != tile_n) {
     // symmetric product (x = w, the affinity): the tile below the diagonal is this tile transposed, written
     // from the same LDS image.  8 lanes cover one 128-byte line of an output row (32 consecutive m), a wave
     // instruction writes 8 rows; the 4 LDS reads behind a store are 2-way conflicted at most.
@@ -364,6 +371,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
     conv_tile_f32<DMA>(p, vec, tm, tn, smem, mirror);
     __syncthreads();              // the next tile refills the LDS stage the epilogue was reading
   }
+}
+
+// 128x64 tiles (each wave 64 x 32) for launches in which whole 128x128 tiles leave CUs idle in the last round: a CU works through its
+// resident workgroups at the matrix pipe's rate whatever their number, so what counts is how evenly the work divides over the 256
+// CUs, and half tiles divide it twice as finely (the MFA conv at 16 segments: 624 tiles = 3 on the busiest CU, 576 us; 1248 half
+// tiles = 5 halves, 509 us).  48 KB of LDS: three workgroups per CU.  Column statistics with two parts per tile (T >= 128).
+// Workgroups b, b + 8, ... (one XCD) take consecutive tiles, column tile fastest (shared A panel).
+__global__ __launch_bounds__(256, 3) void conv_gemm_f32_n64_kernel(const sd_conv_args p, const int vec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n_tiles = (p.cout + 63) / 64;
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int tm = wg / n_tiles;
+  conv_tile_f32<true, 1>(p, vec, tm, wg - tm * n_tiles, smem);
 }
 
 
@@ -630,6 +652,196 @@ __global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const sd_conv_args
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-segment layers of small launches (SE squeeze FC, global-context bias, final FC: M = B <= 256 rows, T = 1, K = 1024 / 6144) with
+// K split over the GRID.  As 32x32 tiles of the kernel above a 6144 -> 128 layer is 4 workgroups that each pull 1.5 MB of operands
+// through one CU (54 us at the ~26 GB/s a CU fetches); here split s of tile t is a workgroup of its own (its 4 waves split the
+// chunk again), writes its 32x32 partial sums to scratch [tile][split][32][32], and a second launch adds a tile's partials in split
+// order (a fixed order: the result does not depend on timing) and applies the epilogue.  The kernel boundary between the two is the
+// hand-off (no tickets, no fences).
+__global__ __launch_bounds__(256) void seg_gemm_partial_f32_kernel(const sd_conv_args p, const int nsplit, const int groups, float* __restrict__ part) {
+  __shared__ float red[4 * SK_T * SK_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n_tiles = (p.cout + SK_T - 1) / SK_T;
+  const int split = blockIdx.x % nsplit, tile = blockIdx.x / nsplit;
+  const int tile_n = tile % n_tiles, tile_m = tile / n_tiles;
+  const int r = lane & 31, h = lane >> 5;
+  int m = tile_m * SK_T + r; m = m < p.M ? m : p.M - 1;
+  int n = tile_n * SK_T + r; n = n < p.cout ? n : p.cout - 1;
+  // this split's chunk: `groups` k-groups of 8 per wave, 4 waves
+  const int k0 = (split * 4 + wid) * groups * 8 + 4 * h;
+  const float* xa = static_cast<const float*>(p.x) + p.a_col0 + (size_t)m * p.lda;
+  const float* wt = static_cast<const float*>(p.w) + (size_t)n * p.cin_pad;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int g = 0; g < groups; ++g) {
+    const int k = k0 + 8 * g;
+    // past cin only zero-padded weights exist (x is not read there); past cin_pad neither operand does
+    const f32x4 a = k < p.cin ? *reinterpret_cast<const f32x4*>(xa + k) : z4;
+    const f32x4 b = k < p.cin_pad ? *reinterpret_cast<const f32x4*>(wt + k) : z4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+  }
+  float* mine = red + wid * SK_T * SK_LD;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mine[((i & 3) + 8 * (i >> 2) + 4 * h) * SK_LD + r] = acc[i];
+  __syncthreads();
+  const int row = tid >> 3, c0 = (tid & 7) * 4;
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = red[row * SK_LD + c0 + e];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += red[w * SK_T * SK_LD + row * SK_LD + c0 + e];
+    v[e] = t;
+  }
+  *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * SK_T + row) * SK_T + c0) = v;
+}
+
+// one workgroup per quarter tile (8 rows x 32 columns, one output per thread): sum over the splits in order, then the epilogue of
+// the 32x32 kernel (no tee: the per-segment layers have none)
+__global__ __launch_bounds__(256) void seg_gemm_reduce_f32_kernel(const sd_conv_args p, const int nsplit, const float* __restrict__ part) {
+  const int tid = threadIdx.x;
+  const int n_tiles = (p.cout + SK_T - 1) / SK_T;
+  const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;
+  const int tile_n = tile % n_tiles, tile_m = tile / n_tiles;
+  const int row = q * 8 + (tid >> 5), col = tid & 31;
+  const int mo = tile_m * SK_T + row, no = tile_n * SK_T + col;
+  const float* src = part + ((size_t)tile * nsplit * SK_T + row) * SK_T + col;
+  float v = 0.f;
+#pragma unroll 8
+  for (int s2 = 0; s2 < nsplit; ++s2) v += src[(size_t)s2 * SK_T * SK_T];
+  if (mo >= p.M || no >= p.cout) return;
+  if (p.bias) v += p.bias_per_seg ? p.bias[(size_t)(mo / p.T) * p.cout + no] : p.bias[no];
+  v = sd_apply_act(v, p.act);
+  v = v * (p.scale ? p.scale[no] : 1.f) + (p.shift ? p.shift[no] : 0.f);
+  v = sd_apply_act(v, p.act2);
+  static_cast<float*>(p.y)[(size_t)mo * p.ldo + p.o_col0 + no] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Time-axis convs of SMALL launches (the reference's own batches: 16-128 segments [REF anti_stick_diarize.py:134,398]): the narrow
+// Res2Net convs and the attention TDNN have cout = 128, so a 32-segment launch is 51 tiles of 128x128 on 256 CUs, and as 32x32
+// tiles of the kernel above every workgroup re-reads 2 x 32 rows of K from L2 for 32 x 32 outputs (79 MB per Res2Net conv).  Here a
+// workgroup owns a 64x64 tile (202 workgroups at 32 segments), 4 waves as 2 x 2 with ONE 32x32 accumulator tile each; a lone
+// workgroup per CU has nothing to hide a fetch behind, so the operands come through an LDS ring of S64_ST stages filled by LDS-DMA
+// (S64_ST - 1 K steps in flight, counted vmcnt waits, one barrier per step).  Same staging layout (128-byte rows, 16-byte chunk
+// c of row r at position c ^ ((r >> 1) & 7)), fragment permutation and epilogue (sd_store_tile) as the 128x128 kernel.
+constexpr int S64_T = 64;
+constexpr int S64_ST = 4;
+constexpr int S64_STAGE = 2 * S64_T * BK;           // floats per stage: 64 A rows + 64 B rows of 32 floats
+constexpr int S64_LDC = S64_T + 4;
+static_assert(S64_T * S64_LDC <= S64_ST * S64_STAGE, "C tile must fit in the ring");
+
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv_args p, const int vec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int n_tiles = (p.cout + S64_T - 1) / S64_T;
+  const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x - tile_m * n_tiles;
+  const int m0 = tile_m * S64_T, n0 = tile_n * S64_T;
+
+  // staging role as in conv_tile_f32<true>: thread (r0 = tid / 8, c4 = tid % 8) fetches position c4 of rows r0 and r0 + 32 of both
+  // operands; the wave's instruction i lands rows 32 i + 8 wid .. + 7
+  const int c4 = tid & 7, r0 = tid >> 3;
+  const int gchunk = (c4 ^ ((r0 >> 1) & 7)) * 4;
+  const int ktot = p.taps * p.cin_pad;
+  const int nk = p.taps * (p.cin_pad / BK);
+  const int half = p.taps / 2;
+  const float* X = static_cast<const float*>(p.x) + p.a_col0;
+  int a_seg[2], a_t[2];
+  const float* wptr[2];
+  const float* aptr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + r0 + 32 * i;
+    m = m < p.M ? m : p.M - 1;
+    const int seg = (m / p.T) * p.T;
+    a_seg[i] = seg;
+    a_t[i] = m - seg;
+    int n = n0 + r0 + 32 * i;
+    n = n < p.cout ? n : p.cout - 1;
+    wptr[i] = static_cast<const float*>(p.w) + (size_t)n * ktot + gchunk;
+  }
+  auto set_tap = [&](int tap) {
+    const int delta = (tap - half) * p.dil;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int tt = a_t[i] + delta;
+      tt = tt < 0 ? -tt : tt;
+      tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
+      aptr[i] = X + (size_t)(a_seg[i] + tt) * p.lda;
+    }
+  };
+  int ld_tap = 0, ld_c0 = 0;
+  set_tap(0);
+  auto issue = [&](int st) {                       // the next K step -> ring stage st: 4 pieces per wave
+    float* As = smem + st * S64_STAGE;
+    float* Bs = As + S64_T * BK;
+    const int col = ld_c0 + gchunk;
+    const int acol = col < p.cin ? col : 0;        // columns past cin meet zero weights
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      SD_GLDS16_F32(aptr[i] + acol, As + (32 * i + 8 * wid) * BK);
+      SD_GLDS16_F32(wptr[i], Bs + (32 * i + 8 * wid) * BK);
+      wptr[i] += BK;
+    }
+    ld_c0 += BK;
+    if (ld_c0 >= p.cin_pad) {
+      ld_c0 = 0;
+      ++ld_tap;
+      if (ld_tap < p.taps) set_tap(ld_tap);
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int frag_row = lane & 31;
+  int doff[4];
+#pragma unroll
+  for (int k8 = 0; k8 < 4; ++k8) doff[k8] = ((2 * k8 + (lane >> 5)) ^ ((frag_row >> 1) & 7)) * 4;
+  const int a_off = (wm * 32 + frag_row) * BK;
+  const int b_off = S64_T * BK + (wn * 32 + frag_row) * BK;
+
+#pragma unroll
+  for (int s = 0; s < S64_ST - 1; ++s)
+    if (s < nk) issue(s);
+  int cur = 0;                                     // stage of step kt
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's pieces of step kt have landed: S64_ST - 2 later steps (4 pieces each) may stay in flight
+    if (kt + S64_ST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (S64_ST - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // everyone's have, and step kt - 1's stage has been read by every wave
+    if (kt + S64_ST - 1 < nk) issue(cur == 0 ? S64_ST - 1 : cur - 1);
+    const float* a = smem + cur * S64_STAGE + a_off;
+    const float* b = smem + cur * S64_STAGE + b_off;
+    f32x4 fa[4], fb[4];
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8) {
+      fa[k8] = *reinterpret_cast<const f32x4*>(a + doff[k8]);
+      fb[k8] = *reinterpret_cast<const f32x4*>(b + doff[k8]);
+    }
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k8][r], fb[k8][r], acc, 0, 0, 0);
+    cur = cur == S64_ST - 1 ? 0 : cur + 1;
+  }
+  __syncthreads();                                 // the ring is free: the C tile goes over it
+  float* Cs = smem;
+  {
+    const int cl = wn * 32 + (lane & 31), hrow = (lane >> 5) * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + hrow) * S64_LDC + cl] = acc[r];
+  }
+  __syncthreads();
+  sd_store_tile<float, S64_T, S64_T, 256, 2, 1>(p, Cs, S64_LDC, m0, n0, tid, vec);
+}
+
 }  // namespace
 
 #ifdef SD_STAMP
@@ -648,6 +860,13 @@ std::atomic<long> g_skinny_below{[] {
 }  // namespace
 
 namespace { std::atomic<long> g_wide_from{1024L}; }
+namespace {
+constexpr long S64_DEFAULT = 256L;
+std::atomic<long> g_s64_below{[] {
+  const char* e = sd_experiment_env("SD_S64_TILES");
+  return e ? atol(e) : S64_DEFAULT;
+}()};
+}  // namespace
 
 extern "C" int sd_set_tuning(int key, long value) {
   if (key == SD_TUNE_SKINNY_TILES) {
@@ -656,6 +875,10 @@ extern "C" int sd_set_tuning(int key, long value) {
   }
   if (key == SD_TUNE_WIDE_TILES) {
     g_wide_from.store(value < 0 ? 1024L : value, std::memory_order_relaxed);
+    return SD_OK;
+  }
+  if (key == SD_TUNE_S64_TILES) {
+    g_s64_below.store(value < 0 ? S64_DEFAULT : value, std::memory_order_relaxed);
     return SD_OK;
   }
   if (key == SD_TUNE_F16_NARROW_TILES) {
@@ -716,6 +939,15 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
     SD_CHECK_ARG(a->M == a->cout && a->T == 1 && a->taps == 1 && !a->bias && !a->scale && !a->shift && !a->tee && !a->colstat &&
                  a->act == SD_ACT_NONE && a->act2 == SD_ACT_NONE && a->cout <= a->ldo - a->o_col0,
                  "sd_conv1d_cl_f32_symmetric: needs a square plain product (M=%d cout=%d)", a->M, a->cout);
+  // time-axis convs of small launches: 64x64 tiles through a 4-stage LDS-DMA ring (SD_TUNE_S64_TILES)
+  if (!a->colstat && !symmetric && a->T > 1 && a->M >= S64_T && tiles_m * tiles_n < g_s64_below.load(std::memory_order_relaxed)) {
+    const long g = (long)((a->M + S64_T - 1) / S64_T) * ((a->cout + S64_T - 1) / S64_T);
+    const size_t lds64 = (size_t)S64_ST * S64_STAGE * sizeof(float);
+    SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_s64_kernel), (int)lds64));
+    hipLaunchKernelGGL(conv_gemm_f32_s64_kernel, dim3((unsigned)g), dim3(256), lds64, static_cast<hipStream_t>(stream), *a, vec);
+    SD_CHECK_LAUNCH("conv_gemm_f32_s64_kernel");
+    return SD_OK;
+  }
   const long skinny_below = g_skinny_below.load(std::memory_order_relaxed);
   if (!a->colstat && tiles_m * tiles_n < skinny_below) {
     const long g = (long)((a->M + SK_T - 1) / SK_T) * ((a->cout + SK_T - 1) / SK_T);
@@ -737,6 +969,26 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
         hipLaunchKernelGGL(conv_gemm_f32_t256_kernel, dim3((unsigned)t256), dim3(512), W_LDS_BYTES, static_cast<hipStream_t>(stream), *a, vec);
       }
       SD_CHECK_LAUNCH("conv_gemm_f32_t256_kernel");
+      return SD_OK;
+    }
+  }
+  // half-width tiles when they shorten the busiest CU's share (SD_F32_N64=0|1, diagnostic: never / whenever possible).  Measured
+  // (tools/probe_tile_alone.py): a launch takes ~15 us + (tiles on the busiest CU) x 62 us per unit of K = 1024, whether the CU's
+  // tiles run side by side or one after the other; a half tile costs 0.52 of a tile
+  {
+    static const int n64 = [] { const char* e = sd_experiment_env("SD_F32_N64"); return e ? atoi(e) : -1; }();
+    const long t128 = tiles_m * tiles_n, t64 = tiles_m * ((a->cout + 63) / 64);
+    const long c128 = (t128 + 255) / 256, c64 = (t64 + 255) / 256;
+    const double cost128 = (double)c128, cost64 = 0.52 * (double)c64;
+    const bool can = !symmetric && (!a->colstat || (a->T >= 128 && a->cout % 64 == 0)) && t64 < (1L << 31);
+    if (can && n64 != 0 && (n64 == 1 || cost64 < 0.97 * cost128)) {
+      const size_t lds64 = (size_t)2 * (BM + 64) * BK * sizeof(float);
+      SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_n64_kernel), (int)lds64));
+      {
+        SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream), 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
+        hipLaunchKernelGGL(conv_gemm_f32_n64_kernel, dim3((unsigned)t64), dim3(256), lds64, static_cast<hipStream_t>(stream), *a, vec);
+      }
+      SD_CHECK_LAUNCH("conv_gemm_f32_n64_kernel");
       return SD_OK;
     }
   }
@@ -778,5 +1030,28 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
                          static_cast<hipStream_t>(stream), *a, vec, ord, (int)ntiles);
   }
   SD_CHECK_LAUNCH("conv_gemm_f32_kernel");
+  return SD_OK;
+}
+
+// Per-segment layer (T == 1) with caller-provided scratch: K split over the grid when the launch is small and K long (the two kernels
+// above), otherwise sd_conv1d_cl_f32.  Internal (sd_common.h): the ECAPA schedule's SE squeeze FC, global-context bias and final FC.
+int sd_seg_gemm_f32(const sd_conv_args* a, void* scratch, size_t scratch_bytes, sd_stream_t stream) {
+  static const bool on = [] { const char* e = sd_experiment_env("SD_SEG_SPLITK"); return !(e && e[0] == '0'); }();
+  if (!on || !a || !scratch || a->T != 1 || a->taps != 1 || a->tee || a->colstat || a->w_dtype != SD_DT_F32 || a->x_dtype != SD_DT_F32 ||
+      a->y_dtype != SD_DT_F32 || a->M <= 0 || a->M > 256 || a->cin_pad < 512 || a->cin_pad % 32 != 0 || a->cin % 4 != 0 || a->lda % 4 != 0 ||
+      a->a_col0 % 4 != 0 || !sd_aligned16(a->x) || !sd_aligned16(a->w) || !sd_aligned16(scratch))
+    return sd_conv1d_cl_f32(a, stream);
+  const long tiles = (long)((a->M + SK_T - 1) / SK_T) * ((a->cout + SK_T - 1) / SK_T);
+  // a split = 4 waves x `groups` k-groups of 8: 256 values of K for the long layers, 128 below 2048
+  const int groups = a->cin_pad >= 2048 ? 8 : 4;
+  const int nsplit = (a->cin_pad + 32 * groups - 1) / (32 * groups);
+  if (nsplit < 2 || (size_t)tiles * nsplit * SK_T * SK_T * sizeof(float) > scratch_bytes || a->M % a->T != 0 || a->cout <= 0 ||
+      a->o_col0 < 0 || a->o_col0 + a->cout > a->ldo || a->a_col0 + a->cin > a->lda)
+    return sd_conv1d_cl_f32(a, stream);
+  float* part = static_cast<float*>(scratch);
+  hipLaunchKernelGGL(seg_gemm_partial_f32_kernel, dim3((unsigned)(tiles * nsplit)), dim3(256), 0, static_cast<hipStream_t>(stream), *a, nsplit, groups, part);
+  SD_CHECK_LAUNCH("seg_gemm_partial_f32_kernel");
+  hipLaunchKernelGGL(seg_gemm_reduce_f32_kernel, dim3((unsigned)(tiles * 4)), dim3(256), 0, static_cast<hipStream_t>(stream), *a, nsplit, part);
+  SD_CHECK_LAUNCH("seg_gemm_reduce_f32_kernel");
   return SD_OK;
 }

@@ -39,6 +39,7 @@ struct Buffers {
   void* rs;                                            // split16 mode: the Res2Net output r as SD_DT_SPLIT16 (tdnn2's input), written by the narrow convs
   void* wpk; size_t wpk_bytes;                        // Res2Net chain weights in fragment order (f16 path)
   float *semean, *seh, *gate, *stats, *gbias, *pooled;
+  void* skp; size_t skp_bytes;                          // partial sums of the per-segment layers' grid split-K (sd_seg_gemm_f32)
   size_t bytes;
 };
 
@@ -66,6 +67,8 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.stats = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
   b.gbias = static_cast<float*>(c.take((size_t)B * w->att_channels, 4));
   b.pooled = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
+  b.skp_bytes = B <= 256 ? (size_t)4 << 20 : 0;
+  b.skp = c.take(b.skp_bytes, 1);
   b.wpk_bytes = act_dtype == SD_DT_F16 ? sd_res2net_chain_workspace_bytes(w->res2_scale - 1) : 0;
   b.wpk = c.take(b.wpk_bytes, 1);
   b.xs = (w->split16 == 1 && act_dtype == SD_DT_F32) ? c.take(M * (size_t)((Cm + 31) / 32 * 32), 4) : nullptr;
@@ -310,7 +313,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // squeeze-excitation gate (per-segment, f32)
     {
       sd_conv_args a = conv_of(blk.se1, b.semean, F32, C, 0, b.seh, F32, blk.se1.cout, 0, B, 1, SD_ACT_RELU);
-      SD_TRY(run_conv(a, stream));
+      SD_TRY(sd_seg_gemm_f32(&a, b.skp_bytes ? b.skp : nullptr, b.skp_bytes, stream));
       sd_conv_args a2 = conv_of(blk.se2, b.seh, F32, blk.se1.cout, 0, b.gate, F32, C, 0, B, 1, SD_ACT_SIGMOID);
       SD_TRY(run_conv(a2, stream));
     }
@@ -347,7 +350,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   {
     sd_conv_args g = conv_of(w->asp_tdnn_g, b.stats, F32, 2 * Cm, 0, b.gbias, F32, w->att_channels, 0, B, 1, SD_ACT_NONE);
     g.scale = nullptr; g.shift = nullptr;
-    SD_TRY(run_conv(g, stream));
+    SD_TRY(sd_seg_gemm_f32(&g, b.skp_bytes ? b.skp : nullptr, b.skp_bytes, stream));
     sd_conv_args a = conv_of(w->asp_tdnn_h, b.h, dt, Cm, 0, b.a1, dt, w->att_channels, 0, M, T, SD_ACT_RELU);
     a.bias = b.gbias; a.bias_per_seg = 1; a.act2 = SD_ACT_TANH;
     SD_TRY(run_narrow(w->asp_tdnn_h, a, split, stream));
@@ -373,7 +376,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   // asp_bn (folded into the weights by the host) + fc
   {
     sd_conv_args a = conv_of(w->fc, b.pooled, F32, 2 * Cm, 0, emb, F32, w->emb_dim, 0, B, 1, SD_ACT_NONE);
-    SD_TRY(run_conv(a, stream));
+    SD_TRY(sd_seg_gemm_f32(&a, b.skp_bytes ? b.skp : nullptr, b.skp_bytes, stream));
   }
   return SD_OK;
 }

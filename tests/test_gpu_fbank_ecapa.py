@@ -137,14 +137,18 @@ def test_fbank_short_segments_and_errors(dev):
         fbank_device(torch.zeros(1600, device=dev), plan)
 
 
-@pytest.fixture(params=["auto", "tiles128", "wide256"])
+@pytest.fixture(params=["auto", "split32", "tiles128", "wide256"])
 def conv_kernel(request):
     """"tiles128" pins the 128x128 f32 conv kernel; "auto" lets small launches take the 32x32 split-K kernel."""
     from speech_diarization_amd import _native as N
     lib = N.load()
-    N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, 0 if request.param != "auto" else -1), "sd_set_tuning")
+    # "auto": small launches take the 64x64 ring kernel (time-axis convs) or the 32x32 split-K kernel (per-segment layers);
+    # "split32": the 32x32 split-K kernel for both
+    N.check(lib.sd_set_tuning(N.SD_TUNE_S64_TILES, 0 if request.param != "auto" else -1), "sd_set_tuning")
+    N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, 0 if request.param not in ("auto", "split32") else -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, 0 if request.param == "wide256" else -1), "sd_set_tuning")   # cout >= 1024 layers: the 256x256 ring kernel
     yield request.param
+    N.check(lib.sd_set_tuning(N.SD_TUNE_S64_TILES, -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, -1), "sd_set_tuning")
 

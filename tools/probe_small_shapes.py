@@ -35,8 +35,10 @@ for B in [int(v) for v in sys.argv[1:]] or [16, 32, 128]:
               ("gbias 6144->128", B, 1, 6144, 128, 1, 1), ("fc 6144->192", B, 1, 6144, 192, 1, 1), ("att tdnn 3072->128", B * 201, 201, 3072, 128, 1, 1)]
     for name, M, T, cin, cout, taps, dil in shapes:
         res = []
-        for label, val in (("default", -1), ("128x128 kernel", 0)):
+        for label, s64, val in (("default", -1, -1), ("64x64 ring", 1 << 30, -1), ("32x32 split-K", 0, -1), ("128x128", 0, 0)):
+            N.check(lib.sd_set_tuning(N.SD_TUNE_S64_TILES, s64), "tune")
             N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, val), "tune")
             res.append(f"{label} {time_conv(M, T, cin, cout, taps, dil):7.1f} us")
         N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, -1), "tune")
+        N.check(lib.sd_set_tuning(N.SD_TUNE_S64_TILES, -1), "tune")
         print(f"B={B:4d} {name:22s} M={M:6d}: " + "   ".join(res), flush=True)
