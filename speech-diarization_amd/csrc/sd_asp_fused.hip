@@ -459,7 +459,11 @@ template <int NT, bool SPLIT = false>
 int launch_f32(const void* a1, const void* wc, const void* h, int ldh, int B, int T, int C, float eps, float* out, hipStream_t s, float wscale = 256.f) {
   auto kern = asp_attend_pool_f32_kernel<NT, SPLIT>;
   const size_t lds = SPLIT ? (size_t)2 * NT * 16 * SLD * sizeof(_Float16) : (size_t)NT * 16 * FLD * sizeof(float);
-  const int cpb = C % 512 == 0 ? 512 : 256;
+  // channels per workgroup (one workgroup per CU: the a1 tile fills most of the LDS; a wave takes ~13 us per 16-channel group):
+  // 512 (four groups per wave) for launches that fill the chip anyway, fewer while the launch still fits one round of the 256 CUs
+  // (16 segments x 3072 channels: 96 workgroups of 512 -> 192 of 256: 64 -> 33 us); every channel is computed alike whatever the split
+  int cpb = C % 512 == 0 ? 512 : 256;
+  while (cpb > 128 && C % (cpb / 2) == 0 && (long)B * (C / (cpb / 2)) <= 256) cpb /= 2;
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * (C / cpb))), dim3(512), lds, s, static_cast<const float*>(a1),
                      static_cast<const float*>(wc), static_cast<const float*>(h), ldh, T, C, cpb, eps, out, wscale);

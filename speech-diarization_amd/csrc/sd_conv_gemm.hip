@@ -733,18 +733,25 @@ __global__ __launch_bounds__(256) void seg_gemm_reduce_f32_kernel(const sd_conv_
 constexpr int S64_T = 64;
 constexpr int S64_ST = 4;
 constexpr int S64_STAGE = 2 * S64_T * BK;           // floats per stage: 64 A rows + 64 B rows of 32 floats
-constexpr int S64_LDC = S64_T + 4;
-static_assert(S64_T * S64_LDC <= S64_ST * S64_STAGE, "C tile must fit in the ring");
+static_assert(S64_T * (S64_T + 4) <= S64_ST * S64_STAGE, "C tile must fit in the ring");
 
+// TM = 64: the tile above.  TM = 32 (launches of fewer than 128 such tiles, i.e. up to ~16 segments): 32 rows x 64 columns, twice the
+// workgroups; waves 0-1 take the first half of every K step's 32 values, waves 2-3 the second, and the two partial tiles are added
+// through LDS (first half + second half: a fixed order).
+template <int TM>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv_args p, const int vec) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int STAGE = (TM + S64_T) * BK;         // floats per stage
+  constexpr int NA = TM / 32;                      // staging instructions per wave for the activation rows
+  constexpr int PIECES = NA + 2;                   // LDS-DMA pieces per wave and stage
+  constexpr int LDCS = S64_T + 4;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = TM == 64 ? wid >> 1 : 0, wn = wid & 1, kh = TM == 64 ? 0 : wid >> 1;
   const int n_tiles = (p.cout + S64_T - 1) / S64_T;
   const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x - tile_m * n_tiles;
-  const int m0 = tile_m * S64_T, n0 = tile_n * S64_T;
+  const int m0 = tile_m * TM, n0 = tile_n * S64_T;
 
-  // staging role as in conv_tile_f32<true>: thread (r0 = tid / 8, c4 = tid % 8) fetches position c4 of rows r0 and r0 + 32 of both
+  // staging role as in conv_tile_f32<true>: thread (r0 = tid / 8, c4 = tid % 8) fetches position c4 of rows r0 (and r0 + 32) of the
   // operands; the wave's instruction i lands rows 32 i + 8 wid .. + 7
   const int c4 = tid & 7, r0 = tid >> 3;
   const int gchunk = (c4 ^ ((r0 >> 1) & 7)) * 4;
@@ -752,16 +759,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
   const int nk = p.taps * (p.cin_pad / BK);
   const int half = p.taps / 2;
   const float* X = static_cast<const float*>(p.x) + p.a_col0;
-  int a_seg[2], a_t[2];
+  int a_seg[NA], a_t[NA];
   const float* wptr[2];
-  const float* aptr[2];
+  const float* aptr[NA];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int m = m0 + r0 + 32 * i;
-    m = m < p.M ? m : p.M - 1;
-    const int seg = (m / p.T) * p.T;
-    a_seg[i] = seg;
-    a_t[i] = m - seg;
+    if (i < NA) {
+      int m = m0 + r0 + 32 * i;
+      m = m < p.M ? m : p.M - 1;
+      const int seg = (m / p.T) * p.T;
+      a_seg[i < NA ? i : 0] = seg;
+      a_t[i < NA ? i : 0] = m - seg;
+    }
     int n = n0 + r0 + 32 * i;
     n = n < p.cout ? n : p.cout - 1;
     wptr[i] = static_cast<const float*>(p.w) + (size_t)n * ktot + gchunk;
@@ -769,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
   auto set_tap = [&](int tap) {
     const int delta = (tap - half) * p.dil;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       int tt = a_t[i] + delta;
       tt = tt < 0 ? -tt : tt;
       tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
@@ -778,14 +787,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
   };
   int ld_tap = 0, ld_c0 = 0;
   set_tap(0);
-  auto issue = [&](int st) {                       // the next K step -> ring stage st: 4 pieces per wave
-    float* As = smem + st * S64_STAGE;
-    float* Bs = As + S64_T * BK;
+  auto issue = [&](int st) {                       // the next K step -> ring stage st
+    float* As = smem + st * STAGE;
+    float* Bs = As + TM * BK;
     const int col = ld_c0 + gchunk;
     const int acol = col < p.cin ? col : 0;        // columns past cin meet zero weights
 #pragma unroll
+    for (int i = 0; i < NA; ++i) SD_GLDS16_F32(aptr[i] + acol, As + (32 * i + 8 * wid) * BK);
+#pragma unroll
     for (int i = 0; i < 2; ++i) {
-      SD_GLDS16_F32(aptr[i] + acol, As + (32 * i + 8 * wid) * BK);
       SD_GLDS16_F32(wptr[i], Bs + (32 * i + 8 * wid) * BK);
       wptr[i] += BK;
     }
@@ -801,32 +811,33 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int frag_row = lane & 31;
-  int doff[4];
+  constexpr int NK8 = TM == 64 ? 4 : 2;            // k groups of 8 per wave and step
+  int doff[NK8];
 #pragma unroll
-  for (int k8 = 0; k8 < 4; ++k8) doff[k8] = ((2 * k8 + (lane >> 5)) ^ ((frag_row >> 1) & 7)) * 4;
+  for (int k8 = 0; k8 < NK8; ++k8) doff[k8] = ((2 * (k8 + NK8 * kh) + (lane >> 5)) ^ ((frag_row >> 1) & 7)) * 4;
   const int a_off = (wm * 32 + frag_row) * BK;
-  const int b_off = S64_T * BK + (wn * 32 + frag_row) * BK;
+  const int b_off = TM * BK + (wn * 32 + frag_row) * BK;
 
 #pragma unroll
   for (int s = 0; s < S64_ST - 1; ++s)
     if (s < nk) issue(s);
   int cur = 0;                                     // stage of step kt
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's pieces of step kt have landed: S64_ST - 2 later steps (4 pieces each) may stay in flight
-    if (kt + S64_ST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (S64_ST - 2)) : "memory");
+    // this wave's pieces of step kt have landed: S64_ST - 2 later steps may stay in flight
+    if (kt + S64_ST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (S64_ST - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                               // everyone's have, and step kt - 1's stage has been read by every wave
     if (kt + S64_ST - 1 < nk) issue(cur == 0 ? S64_ST - 1 : cur - 1);
-    const float* a = smem + cur * S64_STAGE + a_off;
-    const float* b = smem + cur * S64_STAGE + b_off;
-    f32x4 fa[4], fb[4];
+    const float* a = smem + cur * STAGE + a_off;
+    const float* b = smem + cur * STAGE + b_off;
+    f32x4 fa[NK8], fb[NK8];
 #pragma unroll
-    for (int k8 = 0; k8 < 4; ++k8) {
+    for (int k8 = 0; k8 < NK8; ++k8) {
       fa[k8] = *reinterpret_cast<const f32x4*>(a + doff[k8]);
       fb[k8] = *reinterpret_cast<const f32x4*>(b + doff[k8]);
     }
 #pragma unroll
-    for (int k8 = 0; k8 < 4; ++k8)
+    for (int k8 = 0; k8 < NK8; ++k8)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k8][r], fb[k8][r], acc, 0, 0, 0);
     cur = cur == S64_ST - 1 ? 0 : cur + 1;
@@ -835,11 +846,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
   float* Cs = smem;
   {
     const int cl = wn * 32 + (lane & 31), hrow = (lane >> 5) * 4;
+    float* mine = Cs + kh * TM * LDCS;             // (TM = 32: the second K half's partial tile behind the first's)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + hrow) * S64_LDC + cl] = acc[r];
+    for (int r = 0; r < 16; ++r) mine[(wm * 32 + (r & 3) + 8 * (r >> 2) + hrow) * LDCS + cl] = acc[r];
   }
   __syncthreads();
-  sd_store_tile<float, S64_T, S64_T, 256, 2, 1>(p, Cs, S64_LDC, m0, n0, tid, vec);
+  if (TM == 32) {
+    for (int i = tid; i < TM * S64_T; i += 256) {
+      const int o = (i >> 6) * LDCS + (i & 63);
+      Cs[o] += Cs[TM * LDCS + o];
+    }
+    __syncthreads();
+  }
+  sd_store_tile<float, TM, S64_T, 256, 2, 0>(p, Cs, LDCS, m0, n0, tid, vec);
 }
 
 }  // namespace
@@ -941,10 +960,17 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
                  "sd_conv1d_cl_f32_symmetric: needs a square plain product (M=%d cout=%d)", a->M, a->cout);
   // time-axis convs of small launches: 64x64 tiles through a 4-stage LDS-DMA ring (SD_TUNE_S64_TILES)
   if (!a->colstat && !symmetric && a->T > 1 && a->M >= S64_T && tiles_m * tiles_n < g_s64_below.load(std::memory_order_relaxed)) {
-    const long g = (long)((a->M + S64_T - 1) / S64_T) * ((a->cout + S64_T - 1) / S64_T);
+    const long nt64 = (a->cout + S64_T - 1) / S64_T;
+    const long g = (long)((a->M + S64_T - 1) / S64_T) * nt64;
     const size_t lds64 = (size_t)S64_ST * S64_STAGE * sizeof(float);
-    SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_s64_kernel), (int)lds64));
-    hipLaunchKernelGGL(conv_gemm_f32_s64_kernel, dim3((unsigned)g), dim3(256), lds64, static_cast<hipStream_t>(stream), *a, vec);
+    static const int s32 = [] { const char* e = sd_experiment_env("SD_S64_HALF"); return e ? atoi(e) : -1; }();   // 0 | 1: never / always 32-row tiles
+    if (s32 != 0 && (s32 == 1 || g < 128)) {
+      SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_s64_kernel<32>), (int)lds64));
+      hipLaunchKernelGGL(conv_gemm_f32_s64_kernel<32>, dim3((unsigned)(((a->M + 31) / 32) * nt64)), dim3(256), lds64, static_cast<hipStream_t>(stream), *a, vec);
+    } else {
+      SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_s64_kernel<64>), (int)lds64));
+      hipLaunchKernelGGL(conv_gemm_f32_s64_kernel<64>, dim3((unsigned)g), dim3(256), lds64, static_cast<hipStream_t>(stream), *a, vec);
+    }
     SD_CHECK_LAUNCH("conv_gemm_f32_s64_kernel");
     return SD_OK;
   }

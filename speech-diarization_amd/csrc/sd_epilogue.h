@@ -197,7 +197,7 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
   constexpr int RPP = NT / TPR;     // rows per pass
   constexpr int PASSES = ROWS / RPP;
   static_assert(ROWS % RPP == 0, "tile rows must be a multiple of the rows covered per pass");
-  static_assert(2 * STAT_PARTS * RPP * COLS <= ROWS * COLS, "column statistics are combined inside the C tile");
+  static_assert(2 * STAT_PARTS * RPP * COLS <= ROWS * COLS, "column statistics are combined inside the C tile");   // (STAT_PARTS = 0: a kernel without them)
   if (!vec) {
     sd_store_tile_scalar<TO, ROWS, COLS, NT>(p, Cs, ldc, m0, n0, tid);
     return;
@@ -256,17 +256,18 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
     if (full) sd_store_rows<TO, PASSES, RPP, TEE_, TADD_, STAT_, true, 3, YSPLIT>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, RB_, ST_, PASSES); \
     else sd_store_rows<TO, PASSES, RPP, TEE_, TADD_, STAT_, false, 3, YSPLIT>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, RB_, ST_, np);        \
   } while (0)
-  if (p.colstat) {
+  if (STAT_PARTS > 0 && p.colstat) {
+    constexpr int SP = STAT_PARTS > 0 ? STAT_PARTS : 1;
     // (host: only with relu / identity, a per-channel bias, cout % COLS == 0, no tee and T >= ROWS / 2, so
     // this branch is uniform over the workgroup, nobody returned above, and a tile spans <= 3 segments)
-    float st[2 * STAT_PARTS][8];          // [sum | sum of squares] x [first, second(, third) segment of the tile]
+    float st[2 * SP][8];          // [sum | sum of squares] x [first, second(, third) segment of the tile]
 #pragma unroll
-    for (int k = 0; k < 2 * STAT_PARTS; ++k)
+    for (int k = 0; k < 2 * SP; ++k)
 #pragma unroll
       for (int e = 0; e < 8; ++e) st[k][e] = 0.f;
     const int rb = p.T - m0 % p.T;          // first tile row of the next segment (>= ROWS: none)
     if (full) {
-      sd_store_rows<TO, PASSES, RPP, false, false, true, true, STAT_PARTS>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, rb, st, PASSES);
+      sd_store_rows<TO, PASSES, RPP, false, false, true, true, SP>(p, c, ldc, row0, n8, b8, s8, h8, lo, rr0, rb, st, PASSES);
     } else {
       // the one tile that hangs over row M: predicated stores, then a rolled pass over this thread's
       // existing rows for the statistics (keeps the unrolled variant's registers out of the common path)
@@ -281,27 +282,27 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
         for (int e = 0; e < 8; ++e) {
           const float x = fmaxf(v[e] + b8[e], lo) * s8[e];     // = y - shift
 #pragma unroll
-          for (int q = 0; q < STAT_PARTS; ++q) {
+          for (int q = 0; q < SP; ++q) {
             st[q][e] += part == q ? x : 0.f;
-            st[STAT_PARTS + q][e] += part == q ? x * x : 0.f;
+            st[SP + q][e] += part == q ? x * x : 0.f;
           }
         }
       }
     }
     // combine the RPP row groups through LDS in a fixed order, then one writer per (quantity, column)
     __syncthreads();                        // every thread has consumed its part of the C tile
-    float* red = Cs;                        // [2 * STAT_PARTS][RPP][COLS]
+    float* red = Cs;                        // [2 * SP][RPP][COLS]
 #pragma unroll
-    for (int k = 0; k < 2 * STAT_PARTS; ++k) SdOut<float>::store8(red + ((size_t)k * RPP + rr0) * COLS + cq, st[k]);
+    for (int k = 0; k < 2 * SP; ++k) SdOut<float>::store8(red + ((size_t)k * RPP + rr0) * COLS + cq, st[k]);
     __syncthreads();
     // colstat unit: [sum part 0..2 | sum of squares part 0..2][cout]; a 2-part kernel leaves slots 2 and 5 alone
     float* dst = p.colstat + (size_t)(m0 / ROWS) * 6 * p.cout + n0;
-    for (int idx = tid; idx < 2 * STAT_PARTS * COLS; idx += NT) {
+    for (int idx = tid; idx < 2 * SP * COLS; idx += NT) {
       const int k = idx / COLS, col = idx - k * COLS;
       float a = 0.f;
 #pragma unroll
       for (int g = 0; g < RPP; ++g) a += red[((size_t)k * RPP + g) * COLS + col];
-      const int slot = k < STAT_PARTS ? k : 3 + (k - STAT_PARTS);
+      const int slot = k < SP ? k : 3 + (k - SP);
       dst[(size_t)slot * p.cout + col] = a;
     }
     __syncthreads();                        // the caller may refill the tile

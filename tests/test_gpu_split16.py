@@ -173,7 +173,10 @@ def test_conv1d_cl_split16_narrow_epilogues(dev):
     kw = dict(cin=cin, bias=gb, bias_per_seg=True, act="relu", scale=scale, shift=shift, act2="tanh")
     ys = ops.conv1d_cl_split16(x, ws2, s2, T, narrow=True, **kw)
     y32 = ops.conv1d_cl(x, ops.pack_weight(w2, dev), T, **kw)
-    assert (ys - y32).abs().max() < 2e-6
+    # both against float64 (two f32-level results differ by the sum of their errors, which depends on the exact kernel's summation order)
+    ref = torch.tanh(torch.relu(x.cpu().double() @ w2[:, :, 0].double().T + gb.cpu().double().repeat_interleave(T, 0)) * scale.cpu().double() + shift.cpu().double())
+    assert (ys.cpu().double() - ref).abs().max() < 2e-6 and (y32.cpu().double() - ref).abs().max() < 2e-6
+    assert (ys - y32).abs().max() < 4e-6
 
 
 def test_narrow_split16_conv_writes_split_output(dev):
