@@ -205,7 +205,8 @@ int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int C, float m
  * fraction of one round of big tiles: default 128 = up to 32 two-second segments; 0 = always the 256x256 kernel; negative = default). */
 #define SD_TUNE_F16_NARROW_TILES 3
 /* SD_TUNE_S64_TILES: sd_conv1d_cl_f32 launches with T > 1, at least 64 rows and fewer 128x128 tiles than `value` (and no column
- * statistics) run the 64x64 ring kernel: the time-axis convs of small batches (default 256; 0 = never; negative = default). */
+ * statistics) run the 64x64 ring kernel (32x64 tiles below 128 workgroups): the time-axis convs of small batches (default 128; 0 = never;
+ * negative = default). */
 #define SD_TUNE_S64_TILES 4
 int sd_set_tuning(int key, long value);
 /* floats needed for sd_conv_args.colstat */
