@@ -51,7 +51,7 @@ typedef void* sd_stream_t; /* hipStream_t */
 #define SD_ERR_WORKSPACE (-3)
 #define SD_ERR_HIP (-4)
 
-#define SD_ABI_VERSION 8
+#define SD_ABI_VERSION 9
 
 int sd_abi_version(void);
 /* sizeof of the structs below as this library was compiled (which: 0 sd_conv_args, 1 sd_layer, 2 sd_se_res2_block,
@@ -171,6 +171,14 @@ typedef struct {
 } sd_conv_args;
 
 int sd_conv1d_cl_f32(const sd_conv_args* args, sd_stream_t stream);
+/* The same operator with caller-provided scratch, for the per-segment layers of a small batch (T = 1, one tap, M <= 256 rows, cin_pad >= 512:
+ * SE squeeze FC, global-context bias, final FC): K is split over the grid in chunks of 128 (cin_pad < 2048) or 256 values, partial 32x32
+ * tiles go to `scratch`, a second launch adds them in split order and applies the epilogue (deterministic; within f32 rounding of
+ * sd_conv1d_cl_f32).  `scratch` must hold sd_seg_gemm_scratch_bytes(M, cin_pad, cout) bytes, 16-byte aligned, and must not be used by another
+ * stream meanwhile; any other shape, a NULL or short scratch: exactly sd_conv1d_cl_f32. */
+int sd_seg_gemm_f32(const sd_conv_args* args, void* scratch, size_t scratch_bytes, sd_stream_t stream);
+/* bytes of scratch with which sd_seg_gemm_f32 splits K over the grid for this shape; 0 = it would not */
+size_t sd_seg_gemm_scratch_bytes(int M, int cin_pad, int cout);
 int sd_conv1d_cl_f16(const sd_conv_args* args, sd_stream_t stream);
 /* "f32-split16x3": the same operator at f32-level accuracy on the f16 matrix cores.  Every f32 operand value is split
  * v = hi + lo (two f16) and a product is hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16 with f32 accumulation: the
@@ -208,6 +216,9 @@ int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int C, float m
  * statistics) run the 64x64 ring kernel (32x64 tiles below 128 workgroups): the time-axis convs of small batches (default 128; 0 = never;
  * negative = default). */
 #define SD_TUNE_S64_TILES 4
+/* SD_TUNE_HALF_TILES: 128x64 instead of 128x128 tiles in sd_conv1d_cl_f32: 0 = never, 1 = whenever the layer allows (column statistics
+ * need T >= 128), negative = by the rule (when they lower the number of tile times of the busiest CU; the default). */
+#define SD_TUNE_HALF_TILES 5
 int sd_set_tuning(int key, long value);
 /* floats needed for sd_conv_args.colstat */
 size_t sd_colstat_floats(int M, int cout);

@@ -22,9 +22,10 @@ SD_TUNE_SKINNY_TILES = 1
 SD_TUNE_WIDE_TILES = 2
 SD_TUNE_F16_NARROW_TILES = 3
 SD_TUNE_S64_TILES = 4
+SD_TUNE_HALF_TILES = 5
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
-SD_ABI_VERSION = 8
+SD_ABI_VERSION = 9
 SD_PROF_CONV_GEMM, SD_PROF_FBANK, SD_PROF_CONV_WIDE = 0, 1, 2
 
 
@@ -112,6 +113,8 @@ PROTOTYPES = {
     "sd_fbank_f32": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_fbank_windows_f32": (_I, [_P, _P, C.c_longlong, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "sd_conv1d_cl_f32": (_I, [C.POINTER(sd_conv_args), _P]),
+    "sd_seg_gemm_f32": (_I, [C.POINTER(sd_conv_args), _P, _Z, _P]),
+    "sd_seg_gemm_scratch_bytes": (_Z, [_I, _I, _I]),
     "sd_conv1d_cl_f16": (_I, [C.POINTER(sd_conv_args), _P]),
     "sd_conv1d_cl_split16": (_I, [C.POINTER(sd_conv_args), _P]),
     "sd_split16_pack_f32": (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _P]),

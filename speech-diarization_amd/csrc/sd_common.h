@@ -15,7 +15,6 @@ int sd_set_error(int code, const char* fmt, ...);
 std::atomic<long>& sd_f16_narrow_tiles();
 // library-internal entry points
 int sd_conv1d_cl_f32_symmetric(const sd_conv_args* a, sd_stream_t stream);   // sd_conv_gemm.hip: x == w, upper triangle + mirror
-int sd_seg_gemm_f32(const sd_conv_args* a, void* scratch, size_t scratch_bytes, sd_stream_t stream);   // sd_conv_gemm.hip: per-segment layer, K split over the grid
 int sd_affinity_sym_f32(const float* xn, int ldx, int N, int groups, float* out, long ldo, sd_stream_t stream);                          // sd_affinity.hip
 int sd_affinity_sym_split16(const void* xs, int ldx, int N, int groups, float* out, long ldo, float alpha, sd_stream_t stream);   // sd_affinity.hip
 int sd_cast_f32_f16(const float* x, long n, void* y, sd_stream_t stream);           // sd_pool.hip

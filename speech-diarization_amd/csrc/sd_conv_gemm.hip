@@ -882,6 +882,7 @@ std::atomic<long> g_wide_from{1024L};
 // segments (201 tiles) 37 against 34
 constexpr long S64_DEFAULT = 128L;
 std::atomic<long> g_s64_below{tune_env("SD_S64_TILES", S64_DEFAULT)};
+std::atomic<long> g_half_tiles{tune_env("SD_F32_N64", -1L)};     // -1: by the rule; 0 never; 1 whenever possible
 }  // namespace
 
 extern "C" int sd_set_tuning(int key, long value) {
@@ -895,6 +896,10 @@ extern "C" int sd_set_tuning(int key, long value) {
   }
   if (key == SD_TUNE_S64_TILES) {
     g_s64_below.store(value < 0 ? S64_DEFAULT : value, std::memory_order_relaxed);
+    return SD_OK;
+  }
+  if (key == SD_TUNE_HALF_TILES) {
+    g_half_tiles.store(value < 0 ? -1L : (value ? 1L : 0L), std::memory_order_relaxed);
     return SD_OK;
   }
   if (key == SD_TUNE_F16_NARROW_TILES) {
@@ -995,11 +1000,11 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
       return SD_OK;
     }
   }
-  // half-width tiles when they shorten the busiest CU's share (SD_F32_N64=0|1, diagnostic: never / whenever possible).  Measured
+  // half-width tiles when they shorten the busiest CU's share (SD_TUNE_HALF_TILES / SD_F32_N64=0|1: never / whenever possible).  Measured
   // (tools/probe_tile_alone.py): a launch takes ~15 us + (tiles on the busiest CU) x 62 us per unit of K = 1024, whether the CU's
   // tiles run side by side or one after the other; a half tile costs 0.52 of a tile
   {
-    static const int n64 = [] { const char* e = sd_experiment_env("SD_F32_N64"); return e ? atoi(e) : -1; }();
+    const long n64 = g_half_tiles.load(std::memory_order_relaxed);
     const long t128 = tiles_m * tiles_n, t64 = tiles_m * ((a->cout + 63) / 64);
     const long c128 = (t128 + 255) / 256, c64 = (t64 + 255) / 256;
     const double cost128 = (double)c128, cost64 = 0.52 * (double)c64;
@@ -1056,20 +1061,32 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
   return SD_OK;
 }
 
+// a split = 4 waves x `groups` k-groups of 8: 256 values of K for the long layers, 128 below 2048
+static int seg_gemm_shape(int M, int cin_pad, int cout, int* groups, int* nsplit, long* tiles) {
+  if (M <= 0 || M > 256 || cin_pad < 512 || cin_pad % 32 != 0 || cout <= 0) return 0;
+  *groups = cin_pad >= 2048 ? 8 : 4;
+  *nsplit = (cin_pad + 32 * *groups - 1) / (32 * *groups);
+  *tiles = (long)((M + SK_T - 1) / SK_T) * ((cout + SK_T - 1) / SK_T);
+  return *nsplit >= 2;
+}
+
+extern "C" size_t sd_seg_gemm_scratch_bytes(int M, int cin_pad, int cout) {
+  int groups, nsplit; long tiles;
+  if (!seg_gemm_shape(M, cin_pad, cout, &groups, &nsplit, &tiles)) return 0;
+  return (size_t)tiles * nsplit * SK_T * SK_T * sizeof(float);
+}
+
 // Per-segment layer (T == 1) with caller-provided scratch: K split over the grid when the launch is small and K long (the two kernels
-// above), otherwise sd_conv1d_cl_f32.  Internal (sd_common.h): the ECAPA schedule's SE squeeze FC, global-context bias and final FC.
-int sd_seg_gemm_f32(const sd_conv_args* a, void* scratch, size_t scratch_bytes, sd_stream_t stream) {
+// above), otherwise sd_conv1d_cl_f32: the ECAPA schedule's SE squeeze FC, global-context bias and final FC.
+extern "C" int sd_seg_gemm_f32(const sd_conv_args* a, void* scratch, size_t scratch_bytes, sd_stream_t stream) {
   static const bool on = [] { const char* e = sd_experiment_env("SD_SEG_SPLITK"); return !(e && e[0] == '0'); }();
   if (!on || !a || !scratch || a->T != 1 || a->taps != 1 || a->tee || a->colstat || a->w_dtype != SD_DT_F32 || a->x_dtype != SD_DT_F32 ||
       a->y_dtype != SD_DT_F32 || a->M <= 0 || a->M > 256 || a->cin_pad < 512 || a->cin_pad % 32 != 0 || a->cin % 4 != 0 || a->lda % 4 != 0 ||
       a->a_col0 % 4 != 0 || !sd_aligned16(a->x) || !sd_aligned16(a->w) || !sd_aligned16(scratch))
     return sd_conv1d_cl_f32(a, stream);
-  const long tiles = (long)((a->M + SK_T - 1) / SK_T) * ((a->cout + SK_T - 1) / SK_T);
-  // a split = 4 waves x `groups` k-groups of 8: 256 values of K for the long layers, 128 below 2048
-  const int groups = a->cin_pad >= 2048 ? 8 : 4;
-  const int nsplit = (a->cin_pad + 32 * groups - 1) / (32 * groups);
-  if (nsplit < 2 || (size_t)tiles * nsplit * SK_T * SK_T * sizeof(float) > scratch_bytes || a->M % a->T != 0 || a->cout <= 0 ||
-      a->o_col0 < 0 || a->o_col0 + a->cout > a->ldo || a->a_col0 + a->cin > a->lda)
+  int groups, nsplit; long tiles;
+  if (!seg_gemm_shape(a->M, a->cin_pad, a->cout, &groups, &nsplit, &tiles) || (size_t)tiles * nsplit * SK_T * SK_T * sizeof(float) > scratch_bytes ||
+      !a->x || !a->w || !a->y || a->cin <= 0 || a->cin > a->cin_pad || a->o_col0 < 0 || a->o_col0 + a->cout > a->ldo || a->a_col0 < 0 || a->a_col0 + a->cin > a->lda)
     return sd_conv1d_cl_f32(a, stream);
   float* part = static_cast<float*>(scratch);
   hipLaunchKernelGGL(seg_gemm_partial_f32_kernel, dim3((unsigned)(tiles * nsplit)), dim3(256), 0, static_cast<hipStream_t>(stream), *a, nsplit, groups, part);

@@ -90,6 +90,37 @@ def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, T: int, *, cin: int, dil:
     return out
 
 
+def seg_gemm(x: torch.Tensor, w_packed: torch.Tensor, *, cin: int, bias=None, act=None, scale=None, shift=None, act2=None,
+             out: torch.Tensor | None = None, scratch: torch.Tensor | None = None) -> torch.Tensor:
+    """A per-segment layer (one row per segment: SE squeeze FC, global-context bias, final FC) through `sd_seg_gemm_f32`: with `scratch`
+    (f32, `seg_gemm_scratch_bytes` bytes; allocated here when None) K is split over the grid for M <= 256 rows and cin_pad >= 512."""
+    _need_cuda(x, w_packed, bias, scale, shift, out, scratch)
+    lib = N.load()
+    cout, taps, cin_pad = w_packed.shape
+    M = x.shape[0]
+    if taps != 1 or w_packed.dtype != torch.float32 or x.dtype != torch.float32:
+        raise TypeError("seg_gemm: f32 activations and one-tap f32 weights")
+    if out is None:
+        out = torch.empty((M, cout), dtype=torch.float32, device=x.device)
+    need = int(lib.sd_seg_gemm_scratch_bytes(M, cin_pad, cout))
+    if scratch is None and need:
+        scratch = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    a = N.sd_conv_args()
+    a.x, a.lda, a.a_col0 = x.data_ptr(), x.stride(0), 0
+    a.w, a.w_dtype = w_packed.data_ptr(), N.SD_DT_F32
+    a.x_dtype, a.y_dtype = N.SD_DT_F32, N.SD_DT_F32
+    a.y, a.ldo, a.o_col0 = out.data_ptr(), out.stride(0), 0
+    a.M, a.T = M, 1
+    a.cin, a.cin_pad, a.cout, a.taps, a.dil = cin, cin_pad, cout, 1, 1
+    a.bias, a.bias_per_seg = _ptr(bias), 0
+    a.act, a.act2 = _ACT[act], _ACT[act2]
+    a.scale, a.shift = _ptr(scale), _ptr(shift)
+    with torch.cuda.device(x.device):
+        N.check(lib.sd_seg_gemm_f32(C.byref(a), scratch.data_ptr() if scratch is not None else None,
+                                    scratch.numel() * 4 if scratch is not None else 0, _stream(x)), "sd_seg_gemm_f32")
+    return out
+
+
 def split16_pack(x: torch.Tensor, a_col0: int = 0, cin: int | None = None, mul: float = 1.0) -> torch.Tensor:
     """f32 [M, ld] columns [a_col0, a_col0 + cin) -> SD_DT_SPLIT16 rows as an f16 tensor [M, 2 * cin_pad32]
     (per 32 values: [hi x 32 | lo x 32], hi = f16(v), lo = f16(v - hi); padding values zero)."""

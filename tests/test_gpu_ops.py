@@ -24,7 +24,7 @@ def _ref_conv_cl(x, w, b, T, dil):
     return y.transpose(1, 2).reshape(M, -1)
 
 
-@pytest.fixture(params=["auto", "split32", "tiles128", "wide256"])
+@pytest.fixture(params=["auto", "split32", "tiles128", "tiles64", "wide256"])
 def conv_kernel(request):
     """Small launches pick the 32x32 split-K kernel by themselves; "tiles128" pins the 128x128 kernel so that
     both implementations of the operator see every case."""
@@ -35,7 +35,10 @@ def conv_kernel(request):
     N.check(lib.sd_set_tuning(N.SD_TUNE_S64_TILES, 0 if request.param != "auto" else -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, 0 if request.param not in ("auto", "split32") else -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, 0 if request.param == "wide256" else -1), "sd_set_tuning")   # cout >= 1024 layers: the 256x256 ring kernel
+    # 128x64 tiles: by the rule ("auto"), always ("tiles64"), never (the pinned kernels)
+    N.check(lib.sd_set_tuning(N.SD_TUNE_HALF_TILES, {"auto": -1, "split32": -1, "tiles64": 1}.get(request.param, 0)), "sd_set_tuning")
     yield request.param
+    N.check(lib.sd_set_tuning(N.SD_TUNE_HALF_TILES, -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_S64_TILES, -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, -1), "sd_set_tuning")
@@ -86,6 +89,40 @@ def test_conv1d_cl_slices_tee_and_per_segment_bias(dev, conv_kernel):
     assert (out[:, 32:64].cpu().double() - y).abs().max() < 1e-5
     assert out[:, :32].abs().max() == 0 and out[:, 64:].abs().max() == 0
     assert (tee.cpu().double() - (y + xbig[:, 96:128])).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("M,cin,cout", [(32, 6144, 128),      # global-context bias at the reference's batch of 32: 24 splits of 256
+                                        (16, 6144, 192),      # final FC, 6 column tiles
+                                        (128, 1024, 128),     # SE squeeze FC: 8 splits of 128, 4 row tiles
+                                        (7, 1000, 36),        # cin not a multiple of the K step, a ragged last split, cout % 32 != 0
+                                        (200, 2080, 64),      # a last split of 32 values
+                                        (300, 1024, 128),     # more than 256 rows: the plain operator
+                                        (5, 256, 64)])        # K too short to split: the plain operator
+def test_seg_gemm_matches_torch(dev, M, cin, cout):
+    """The per-segment layers with K split over the grid (sd_seg_gemm_f32) against float64, bitwise repeatable, and with no scratch
+    exactly the plain operator."""
+    from speech_diarization_amd import ops, _native as N
+    g = torch.Generator().manual_seed(M + cin)
+    x = torch.randn(M, cin, generator=g, dtype=torch.float64)
+    w = torch.randn(cout, cin, 1, generator=g, dtype=torch.float64) / np.sqrt(cin)
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    scale = torch.rand(cout, generator=g, dtype=torch.float64) + 0.5
+    shift = torch.randn(cout, generator=g, dtype=torch.float64)
+    ref = torch.sigmoid(torch.relu(x @ w[:, :, 0].T + b) * scale + shift)
+    xd, wp = x.float().to(dev), ops.pack_weight(w.float(), dev)
+    kw = dict(cin=cin, bias=b.float().to(dev), act="relu", scale=scale.float().to(dev), shift=shift.float().to(dev), act2="sigmoid")
+    got = ops.seg_gemm(xd, wp, **kw)
+    again = ops.seg_gemm(xd, wp, **kw)
+    plain = ops.conv1d_cl(xd, wp, 1, **kw)
+    torch.cuda.synchronize()
+    assert (got.cpu().double() - ref).abs().max() < 2e-6
+    assert torch.equal(got, again)
+    assert (got - plain).abs().max() < 2e-6
+    need = N.load().sd_seg_gemm_scratch_bytes(M, wp.shape[2], cout)
+    assert (need > 0) == (M <= 256 and wp.shape[2] >= 512)
+    if need:      # a scratch that is too small falls back to the plain operator, bit for bit
+        small = torch.empty(need // 4 - 1, device=dev)
+        assert torch.equal(ops.seg_gemm(xd, wp, scratch=small, **kw), plain)
 
 
 def test_conv1d_cl_rejects_bad_arguments(dev):
