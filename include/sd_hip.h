@@ -219,6 +219,9 @@ int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int C, float m
 /* SD_TUNE_HALF_TILES: 128x64 instead of 128x128 tiles in sd_conv1d_cl_f32: 0 = never, 1 = whenever the layer allows (column statistics
  * need T >= 128), negative = by the rule (when they lower the number of tile times of the busiest CU; the default). */
 #define SD_TUNE_HALF_TILES 5
+/* SD_TUNE_TILE_ROWS: tiles of 80 / 96 / 112 rows x 128 columns in sd_conv1d_cl_f32 (16-row MFMA granularity, for launches whose 128-row
+ * tiles divide badly over the CUs): 0 = never, 80 / 96 / 112 = that height whenever the layer allows, negative = by the rule (the default). */
+#define SD_TUNE_TILE_ROWS 6
 int sd_set_tuning(int key, long value);
 /* floats needed for sd_conv_args.colstat */
 size_t sd_colstat_floats(int M, int cout);

@@ -15,6 +15,9 @@ int sd_set_error(int code, const char* fmt, ...);
 std::atomic<long>& sd_f16_narrow_tiles();
 // library-internal entry points
 int sd_conv1d_cl_f32_symmetric(const sd_conv_args* a, sd_stream_t stream);   // sd_conv_gemm.hip: x == w, upper triangle + mirror
+int sd_conv1d_cl_f32_rows(const sd_conv_args* a, sd_stream_t stream, int* stat_rows);   // sd_conv_gemm.hip: sd_conv1d_cl_f32 that may write colstat in units of *stat_rows rows
+int sd_colstat_finish_rows(const float* colstat, const float* pivot, const void* y, int y_dtype, int ldy, int y_col0, int B, int T, int C, int want_std,
+                           float eps, float* out, int unit_rows, sd_stream_t stream);              // sd_pool.hip: sd_colstat_finish_dt for such units
 int sd_affinity_sym_f32(const float* xn, int ldx, int N, int groups, float* out, long ldo, sd_stream_t stream);                          // sd_affinity.hip
 int sd_affinity_sym_split16(const void* xs, int ldx, int N, int groups, float* out, long ldo, float alpha, sd_stream_t stream);   // sd_affinity.hip
 int sd_cast_f32_f16(const float* x, long n, void* y, sd_stream_t stream);           // sd_pool.hip

@@ -373,6 +373,139 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const sd_conv_arg
   }
 }
 
+// Tiles of 16 J rows x 128 columns (J = 5, 6, 7: 80, 96, 112 rows) for launches whose 128-row tiles divide badly over the 256 CUs: a launch
+// costs ~15 us + (tile times on the busiest CU), so 408 tiles of 128 rows (a C -> C layer at 32 segments: 2 per CU on 152 CUs) cost what
+// 512 do, and 464 tiles of 112 rows (still 2 per CU) cost 0.875 of that.  16-row granularity needs v_mfma_f32_16x16x4_f32: 4 waves as 1 x 4,
+// each wave all 16 J rows x 32 columns = J x 2 accumulator tiles; a lane reads four consecutive k with one 16-byte access (chunk fq for
+// k 0..15, chunk fq + 4 for k 16..31) and feeds element r to MFMA r, the same permutation on both operands.  Staging (LDS-DMA, two
+// stages, the 128x128 kernel's swizzle), epilogue (sd_store_tile over an LDS C tile) and column statistics (units of 16 J rows) as there.
+template <int J>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_vh_kernel(const sd_conv_args p, const int vec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int VM = 16 * J;
+  constexpr int NAI = (VM + 31) / 32;         // staging instruction slots for the activation rows
+  constexpr int VLDC = BN + 4;
+  static_assert(VM * VLDC <= 2 * (VM + BN) * BK, "C tile must fit in the operand stages");
+  float* const As = smem;                     // [2][VM][BK]
+  float* const Bs = smem + 2 * VM * BK;       // [2][BN][BK]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n_tiles = (p.cout + BN - 1) / BN;
+  int wg;
+  {                                           // workgroups b, b + 8, ... (one XCD) take consecutive tiles, column tile fastest
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_m = wg / n_tiles, tile_n = wg - tile_m * n_tiles;
+  const int m0 = tile_m * VM, n0 = tile_n * BN;
+
+  const int c4 = tid & 7, r0 = tid >> 3;
+  const int gchunk = (c4 ^ ((r0 >> 1) & 7)) * 4;
+  const int ktot = p.taps * p.cin_pad;
+  const int nk = p.taps * (p.cin_pad / BK);
+  const int half = p.taps / 2;
+  const float* X = static_cast<const float*>(p.x) + p.a_col0;
+  int a_seg[NAI], a_t[NAI];
+  const float* aptr[NAI];
+  const float* wptr[4];
+#pragma unroll
+  for (int i = 0; i < NAI; ++i) {
+    int m = m0 + r0 + 32 * i;
+    m = m < p.M ? m : p.M - 1;
+    const int seg = (m / p.T) * p.T;
+    a_seg[i] = seg;
+    a_t[i] = m - seg;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int n = n0 + r0 + 32 * i;
+    n = n < p.cout ? n : p.cout - 1;
+    wptr[i] = static_cast<const float*>(p.w) + (size_t)n * ktot + gchunk;
+  }
+  auto set_tap = [&](int tap) {
+    const int delta = (tap - half) * p.dil;
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+      int tt = a_t[i] + delta;
+      tt = tt < 0 ? -tt : tt;
+      tt = tt >= p.T ? 2 * (p.T - 1) - tt : tt;
+      aptr[i] = X + (size_t)(a_seg[i] + tt) * p.lda;
+    }
+  };
+  int ld_tap = 0, ld_c0 = 0;
+  set_tap(0);
+  auto issue = [&](int buf) {
+    const int col = ld_c0 + gchunk;
+    const int acol = col < p.cin ? col : 0;
+#pragma unroll
+    for (int i = 0; i < NAI; ++i)
+      if (32 * i + 8 * wid < VM)              // wave-uniform: this wave's 8 rows of slot i exist
+        SD_GLDS16_F32(aptr[i] + acol, As + buf * VM * BK + (32 * i + 8 * wid) * BK);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      SD_GLDS16_F32(wptr[i], Bs + buf * BN * BK + (32 * i + 8 * wid) * BK);
+      wptr[i] += BK;
+    }
+    ld_c0 += BK;
+    if (ld_c0 >= p.cin_pad) {
+      ld_c0 = 0;
+      ++ld_tap;
+      if (ld_tap < p.taps) set_tap(ld_tap);
+    }
+  };
+
+  f32x4 acc[J][2];
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  // row 16 i + fr (and 32 wid + 16 j + fr) has the swizzle key (fr >> 1) & 7 whatever i, j
+  const int so0 = ((fq ^ ((fr >> 1) & 7)) * 4), so1 = (((fq + 4) ^ ((fr >> 1) & 7)) * 4);
+  const float* const a_base = As + fr * BK;
+  const float* const b_base = Bs + (32 * wid + fr) * BK;
+
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* a = a_base + cur * VM * BK;
+    const float* b = b_base + cur * BN * BK;
+    f32x4 av[2][J], bv[2][2];
+#pragma unroll
+    for (int i = 0; i < J; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(a + 16 * i * BK + so0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(b + 16 * j * BK + so0);
+    if (kt + 1 < nk) issue(cur ^ 1);          // the other stage is free since the barrier that ended step kt - 1
+#pragma unroll
+    for (int i = 0; i < J; ++i) av[1][i] = *reinterpret_cast<const f32x4*>(a + 16 * i * BK + so1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[1][j] = *reinterpret_cast<const f32x4*>(b + 16 * j * BK + so1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][i][r], bv[h][j][r], acc[i][j], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  // acc[i][j][r] = C[16 i + 4 fq + r][32 wid + 16 j + fr]
+  float* Cs = smem;
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(16 * i + 4 * fq + r) * VLDC + 32 * wid + 16 * j + fr] = acc[i][j][r];
+  __syncthreads();
+  sd_store_tile<float, VM, BN, 256, 2, (J >= 6 ? 3 : 2)>(p, Cs, VLDC, m0, n0, tid, vec);
+}
+
 // 128x64 tiles (each wave 64 x 32) for launches in which whole 128x128 tiles leave CUs idle in the last round: a CU works through its
 // resident workgroups at the matrix pipe's rate whatever their number, so what counts is how evenly the work divides over the 256
 // CUs, and half tiles divide it twice as finely (the MFA conv at 16 segments: 624 tiles = 3 on the busiest CU, 576 us; 1248 half
@@ -883,6 +1016,7 @@ std::atomic<long> g_wide_from{1024L};
 constexpr long S64_DEFAULT = 128L;
 std::atomic<long> g_s64_below{tune_env("SD_S64_TILES", S64_DEFAULT)};
 std::atomic<long> g_half_tiles{tune_env("SD_F32_N64", -1L)};     // -1: by the rule; 0 never; 1 whenever possible
+std::atomic<long> g_tile_rows{tune_env("SD_F32_TILE_ROWS", -1L)};  // -1: by the rule; 0: 128-row tiles only; 80 / 96 / 112: that height whenever possible
 }  // namespace
 
 extern "C" int sd_set_tuning(int key, long value) {
@@ -898,6 +1032,10 @@ extern "C" int sd_set_tuning(int key, long value) {
     g_s64_below.store(value < 0 ? S64_DEFAULT : value, std::memory_order_relaxed);
     return SD_OK;
   }
+  if (key == SD_TUNE_TILE_ROWS) {
+    g_tile_rows.store(value < 0 ? -1L : value, std::memory_order_relaxed);
+    return SD_OK;
+  }
   if (key == SD_TUNE_HALF_TILES) {
     g_half_tiles.store(value < 0 ? -1L : (value ? 1L : 0L), std::memory_order_relaxed);
     return SD_OK;
@@ -909,15 +1047,22 @@ extern "C" int sd_set_tuning(int key, long value) {
   return sd_set_error(SD_ERR_ARG, "sd_set_tuning: unknown key %d", key);
 }
 
-static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool symmetric);
+static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool symmetric, int* stat_rows = nullptr);
 
 extern "C" int sd_conv1d_cl_f32(const sd_conv_args* a, sd_stream_t stream) { return conv1d_cl_f32_impl(a, stream, false); }
+
+// The same for a caller that can take the column statistics in units other than 128 rows (internal, sd_common.h: the ECAPA schedule):
+// *stat_rows receives the unit the launch used (128, or the 80 / 96 / 112 rows of the variable-height kernel), for sd_colstat_finish_rows.
+int sd_conv1d_cl_f32_rows(const sd_conv_args* a, sd_stream_t stream, int* stat_rows) {
+  if (stat_rows) *stat_rows = 128;
+  return conv1d_cl_f32_impl(a, stream, false, stat_rows);
+}
 
 // x == w, M == cout, no epilogue arithmetic: only the tiles on and above the diagonal are computed, each is stored
 // twice (as is and transposed).  Internal (sd_common.h): the affinity's full-matrix call.
 int sd_conv1d_cl_f32_symmetric(const sd_conv_args* a, sd_stream_t stream) { return conv1d_cl_f32_impl(a, stream, true); }
 
-static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool symmetric) {
+static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool symmetric, int* stat_rows) {
   SD_CHECK_ARG(a != nullptr, "sd_conv1d_cl_f32: null args");
   SD_CHECK_ARG(a->w_dtype == SD_DT_F32, "sd_conv1d_cl_f32: w_dtype %d not supported by the f32 operator", a->w_dtype);
   SD_CHECK_ARG(a->x && a->w && a->y, "sd_conv1d_cl_f32: null x/w/y");
@@ -1009,6 +1154,40 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
     const long c128 = (t128 + 255) / 256, c64 = (t64 + 255) / 256;
     const double cost128 = (double)c128, cost64 = 0.52 * (double)c64;
     const bool can = !symmetric && (!a->colstat || (a->T >= 128 && a->cout % 64 == 0)) && t64 < (1L << 31);
+    // tiles of 80 / 96 / 112 rows (SD_TUNE_TILE_ROWS): a tile of 16 J rows costs J / 8 of a 128-row tile
+    {
+      const long rows = g_tile_rows.load(std::memory_order_relaxed);
+      int best = 0;
+      double best_cost = 0.97 * (n64 != 0 && can && cost64 < cost128 ? cost64 : cost128);
+      // (column statistics in units of 16 J rows: only for a caller that asked for the unit)
+      // (T > 1: the time-axis convs.  The 16x16x4 MFMA sums four products per step where the 32x32x2 one sums two, so its results differ
+      // from the other kernels' in the last bit; plain products such as the affinity's row blocks (T = 1) keep the bits of the 128x128 kernel)
+      if (!symmetric && a->T > 1 && (!a->colstat || stat_rows) && rows != 0)
+        for (int j = 5; j <= 7; ++j) {
+          if (a->colstat && a->T < (j == 5 ? 80 : 8 * j)) continue;      // a tile may span two (J = 5) / three segments
+          const long tj = ((a->M + 16 * j - 1) / (16 * j)) * tiles_n;
+          const double cj = (double)((tj + 255) / 256) * (double)j / 8.0 * 1.02;
+          if (rows == 16 * j || (rows < 0 && cj < best_cost)) { best = j; best_cost = cj; }
+        }
+      if (best) {
+        const long tj = ((a->M + 16 * best - 1) / (16 * best)) * tiles_n;
+        const size_t ldsv = (size_t)2 * (16 * best + BN) * BK * sizeof(float);
+        const void* fn = best == 5 ? reinterpret_cast<const void*>(conv_gemm_f32_vh_kernel<5>)
+                       : best == 6 ? reinterpret_cast<const void*>(conv_gemm_f32_vh_kernel<6>) : reinterpret_cast<const void*>(conv_gemm_f32_vh_kernel<7>);
+        SD_CHECK_HIP(sd_func_max_lds(fn, (int)ldsv));
+        {
+          SdProfScope prof(SD_PROF_CONV_GEMM, static_cast<hipStream_t>(stream), 2.0 * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
+          const dim3 grid((unsigned)tj), block(256);
+          hipStream_t hs = static_cast<hipStream_t>(stream);
+          if (best == 5) hipLaunchKernelGGL(conv_gemm_f32_vh_kernel<5>, grid, block, ldsv, hs, *a, vec);
+          else if (best == 6) hipLaunchKernelGGL(conv_gemm_f32_vh_kernel<6>, grid, block, ldsv, hs, *a, vec);
+          else hipLaunchKernelGGL(conv_gemm_f32_vh_kernel<7>, grid, block, ldsv, hs, *a, vec);
+        }
+        SD_CHECK_LAUNCH("conv_gemm_f32_vh_kernel");
+        if (stat_rows) *stat_rows = 16 * best;
+        return SD_OK;
+      }
+    }
     if (can && n64 != 0 && (n64 == 1 || cost64 < 0.97 * cost128)) {
       const size_t lds64 = (size_t)2 * (BM + 64) * BK * sizeof(float);
       SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(conv_gemm_f32_n64_kernel), (int)lds64));

@@ -133,8 +133,12 @@ sd_conv_args conv_of(const sd_layer& l, const void* x, int x_dtype, int lda, int
   return a;
 }
 
-int run_conv(const sd_conv_args& a, sd_stream_t stream) {
-  return a.w_dtype == SD_DT_F16 ? sd_conv1d_cl_f16(&a, stream) : sd_conv1d_cl_f32(&a, stream);
+// stat_rows (optional): receives the row unit of the column statistics the launch wrote (128 unless the exact-f32 operator picked one of
+// its 80 / 96 / 112-row tiles: small launches)
+int run_conv(const sd_conv_args& a, sd_stream_t stream, int* stat_rows = nullptr) {
+  if (stat_rows) *stat_rows = 128;
+  if (a.w_dtype == SD_DT_F16) return sd_conv1d_cl_f16(&a, stream);
+  return stat_rows ? sd_conv1d_cl_f32_rows(&a, stream, stat_rows) : sd_conv1d_cl_f32(&a, stream);
 }
 
 // A wide layer of the f32 schedule: in split16 mode (and when the layer carries the second packing) its f32 input is
@@ -168,8 +172,10 @@ bool wide_goes_narrow(const sd_layer& l, int M, long narrow_tiles) {
 bool wide_packed(const sd_layer& l) { return l.w_split && l.bias_split && l.scale_split; }
 
 // twin / twin_ld: an SD_DT_SPLIT16 copy of a.x that already exists (same value columns a.a_col0 .. of rows of twin_ld value columns)
-int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, long narrow_tiles, sd_stream_t stream, const void* twin = nullptr, int twin_ld = 0) {
+int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, long narrow_tiles, sd_stream_t stream, const void* twin = nullptr, int twin_ld = 0,
+             int* stat_rows = nullptr) {
   const int cp = (l.cin + 31) / 32 * 32;
+  if (stat_rows) *stat_rows = 128;
   if (split && l.w_split && !wide_packed(l)) {
     // narrow packing on a wide-role layer: the weights are scaled by 2^s and NOTHING else carries the scale, so the only split
     // kernel that may take them is the 128x128 one with w_scale_inv (the layer's own bias / scale); otherwise exact f32
@@ -179,12 +185,12 @@ int run_wide(const sd_layer& l, sd_conv_args a, bool split, void* xs, long narro
       a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = cp; a.w_scale_inv = l.split_scale_inv;
       return sd_conv1d_cl_split16(&a, stream);
     }
-    return run_conv(a, stream);
+    return run_conv(a, stream, stat_rows);
   }
   if (!(split && wide_packed(l) && xs && a.x_dtype == SD_DT_F32 && (a.y_dtype == SD_DT_F32 || a.y_dtype == SD_DT_SPLIT16) && !(a.tee && a.tee_add) &&
         !(a.colstat && a.T < 128))) {
     if (a.y_dtype == SD_DT_SPLIT16) return sd_set_error(SD_ERR_UNSUPPORTED, "sd_ecapa_forward: a split output needs the split wide kernel");
-    return run_conv(a, stream);
+    return run_conv(a, stream, stat_rows);
   }
   if (a.y_dtype != SD_DT_SPLIT16 && wide_goes_narrow(l, a.M, narrow_tiles) && !a.colstat && l.cin % 4 == 0 && a.lda % 4 == 0 && a.a_col0 % 4 == 0) {
     a.w = l.w_split; a.w_dtype = SD_DT_SPLIT16; a.cin_pad = cp;           // f32 x stays: split while staged; the folded 2^s
@@ -303,11 +309,13 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // geometry allows (the Res2Net scratch s0 is dead and holds them), else from a pass over t2
     {
       sd_conv_args a = conv_of(blk.tdnn2, b.r, dt, C, 0, b.t2, dt, C, 0, M, T, SD_ACT_RELU);
+      // (units of 80 rows, the smallest tile of the exact-f32 operator, bound the size of the statistics)
       const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && C % 256 == 0 && !(wsplit && blk.tdnn2.w_split && wide_goes_narrow(blk.tdnn2, M, nt)) &&
-                        sd_colstat_floats(M, C) * sizeof(float) <= (size_t)M * chunk * es;
+                        (size_t)((M + 79) / 80) * 6 * C * sizeof(float) <= (size_t)M * chunk * es;
       if (stat) a.colstat = static_cast<float*>(b.s0);
-      SD_TRY(run_wide(blk.tdnn2, a, wsplit, b.xs, nt, stream, r_split ? b.rs : nullptr, C));
-      if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
+      int rows = 128;
+      SD_TRY(run_wide(blk.tdnn2, a, wsplit, b.xs, nt, stream, r_split ? b.rs : nullptr, C, stat ? &rows : nullptr));
+      if (stat) SD_TRY(sd_colstat_finish_rows(a.colstat, a.shift, b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, rows, stream));
       else SD_TRY(sd_seg_mean_std_dt(b.t2, dt, C, 0, B, T, C, 0, 0.f, b.semean, stream));
     }
     // squeeze-excitation gate (per-segment, f32)
@@ -340,10 +348,11 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   {
     sd_conv_args a = conv_of(w->mfa, b.xcat, dt, Cm, 0, b.h, dt, Cm, 0, M, T, SD_ACT_RELU);
     const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && Cm % 256 == 0 && !(wsplit && w->mfa.w_split && wide_goes_narrow(w->mfa, M, nt)) &&
-                      sd_colstat_floats(M, Cm) * sizeof(float) <= (size_t)M * C * es;
+                      (size_t)((M + 79) / 80) * 6 * Cm * sizeof(float) <= (size_t)M * C * es;
     if (stat) a.colstat = static_cast<float*>(b.r);
-    SD_TRY(run_wide(w->mfa, a, wsplit, b.xs, nt, stream, b.xcs, Cm));
-    if (stat) SD_TRY(sd_colstat_finish_dt(a.colstat, a.shift, b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
+    int rows = 128;
+    SD_TRY(run_wide(w->mfa, a, wsplit, b.xs, nt, stream, b.xcs, Cm, stat ? &rows : nullptr));
+    if (stat) SD_TRY(sd_colstat_finish_rows(a.colstat, a.shift, b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, rows, stream));
     else SD_TRY(sd_seg_mean_std_dt(b.h, dt, Cm, 0, B, T, Cm, 1, w->asp_eps, b.stats, stream));
   }
   // attentive statistics pooling with global context

@@ -115,7 +115,7 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
   // LDS rows are fetched and stored in chunks of 4 (1 with the 32 statistics accumulators live: the
   // 256x256 kernel has 128 VGPRs beside its accumulators).  The tee_add rows are GLOBAL loads and must
   // all be issued before the first store (header comment), so they are prefetched for the whole tile.
-  constexpr int CH = STAT ? 1 : (PASSES < 4 ? PASSES : 4);
+  constexpr int CH = STAT ? 1 : (PASSES % 4 == 0 ? 4 : (PASSES < 8 ? PASSES : 1));     // (5, 6, 7 passes: the 80 / 96 / 112-row tiles, in one chunk)
   static_assert(PASSES % CH == 0 && (TEE || !TADD), "");
   TO* const y = static_cast<TO*>(p.y) + row0 * p.ldo + p.o_col0 + n8;
   TO* const tee = TEE ? static_cast<TO*>(p.tee) + row0 * p.ldt + (n8 - p.tee_lo) : nullptr;

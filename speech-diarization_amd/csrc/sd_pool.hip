@@ -350,13 +350,13 @@ int check_cl_dt(const char* fn, const void* x, int dtype, int ld, int col0, int 
   return SD_OK;
 }
 // Column statistics left by the conv epilogue (sd_conv_args.colstat) -> per-segment mean (and std).
-// colstat [units][6][C]: sums of (y - pivot) and (y - pivot)^2 over each 128-row tile, split at the
-// segment boundaries inside the tile (up to three segments: T >= 64) (a trailing partial tile counts its existing rows).  Thread =
-// (segment, channel); the tiles of a segment are added in ascending order.
+// colstat [units][6][C]: sums of (y - pivot) and (y - pivot)^2 over each tile of U rows (128; 80 / 96 / 112 from the variable-height
+// conv kernel), split at the segment boundaries inside the tile (up to three segments: T >= U / 2) (a trailing partial tile counts its
+// existing rows).  Thread = (segment, channel); the tiles of a segment are added in ascending order.
 template <typename T>
 __global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __restrict__ cs, const float* __restrict__ pivot,
                                                              const T* __restrict__ y, int ldy, int Tn, int C, int M,
-                                                             int want_std, float eps, float* __restrict__ out) {
+                                                             int want_std, float eps, float* __restrict__ out, int U) {
   const int cblocks = (C + 255) / 256;
   const int c = (blockIdx.x % cblocks) * 256 + threadIdx.x;
   const int b = blockIdx.x / cblocks;
@@ -364,8 +364,8 @@ __global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __rest
   const int r0 = b * Tn, r1 = r0 + Tn;            // rows of this segment
   const float pv = pivot ? pivot[c] : 0.f;
   float s = 0.f, q = 0.f;
-  for (int u = r0 / 128; u * 128 < r1; ++u) {
-    const int part = b - (u * 128) / Tn;            // this segment is the tile's first, second or third (T >= 64)
+  for (int u = r0 / U; u * U < r1; ++u) {
+    const int part = b - (u * U) / Tn;              // this segment is the tile's first, second or third (T >= U / 2)
     const float* t = cs + (size_t)u * 6 * C + c;
     s += t[(size_t)part * C];
     q += t[(size_t)(3 + part) * C];
@@ -475,7 +475,13 @@ extern "C" size_t sd_colstat_floats(int M, int cout) {
 
 extern "C" int sd_colstat_finish_dt(const float* colstat, const float* pivot, const void* y, int y_dtype, int ldy, int y_col0,
                                     int B, int T, int C, int want_std, float eps, float* out, sd_stream_t stream) {
+  return sd_colstat_finish_rows(colstat, pivot, y, y_dtype, ldy, y_col0, B, T, C, want_std, eps, out, 128, stream);
+}
+
+int sd_colstat_finish_rows(const float* colstat, const float* pivot, const void* y, int y_dtype, int ldy, int y_col0,
+                           int B, int T, int C, int want_std, float eps, float* out, int unit_rows, sd_stream_t stream) {
   SD_CHECK_ARG(colstat && y && out, "sd_colstat_finish_dt: null pointer");
+  SD_CHECK_ARG(unit_rows > 0 && unit_rows <= 128 && 2 * T >= unit_rows, "sd_colstat_finish: unit of %d rows with T=%d", unit_rows, T);
   SD_CHECK_ARG(y_dtype == SD_DT_F32 || y_dtype == SD_DT_F16, "sd_colstat_finish_dt: y_dtype=%d", y_dtype);
   SD_CHECK_ARG(B >= 0 && T >= 64 && C > 0, "sd_colstat_finish_dt: B=%d T=%d (>= 64) C=%d", B, T, C);
   SD_CHECK_ARG((long)B * T < (1L << 31) && y_col0 >= 0 && y_col0 + C <= ldy, "sd_colstat_finish_dt: bad shape");
@@ -485,10 +491,10 @@ extern "C" int sd_colstat_finish_dt(const float* colstat, const float* pivot, co
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (y_dtype == SD_DT_F16)
     hipLaunchKernelGGL(colstat_finish_kernel<_Float16>, grid, dim3(256), 0, s, colstat, pivot, static_cast<const _Float16*>(y) + y_col0, ldy, T, C,
-                       B * T, want_std, eps, out);
+                       B * T, want_std, eps, out, unit_rows);
   else
     hipLaunchKernelGGL(colstat_finish_kernel<float>, grid, dim3(256), 0, s, colstat, pivot, static_cast<const float*>(y) + y_col0, ldy, T, C,
-                       B * T, want_std, eps, out);
+                       B * T, want_std, eps, out, unit_rows);
   SD_CHECK_LAUNCH("colstat_finish_kernel");
   return SD_OK;
 }

@@ -137,7 +137,7 @@ def test_fbank_short_segments_and_errors(dev):
         fbank_device(torch.zeros(1600, device=dev), plan)
 
 
-@pytest.fixture(params=["auto", "split32", "tiles128", "tiles64", "wide256"])
+@pytest.fixture(params=["auto", "split32", "tiles128", "tiles64", "rows80", "rows96", "rows112", "wide256"])
 def conv_kernel(request):
     """"tiles128" pins the 128x128 f32 conv kernel; "auto" lets small launches take the 32x32 split-K kernel."""
     from speech_diarization_amd import _native as N
@@ -149,8 +149,11 @@ def conv_kernel(request):
     N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, 0 if request.param == "wide256" else -1), "sd_set_tuning")   # cout >= 1024 layers: the 256x256 ring kernel
     # 128x64 tiles: by the rule ("auto"), always ("tiles64"), never (the pinned kernels)
     N.check(lib.sd_set_tuning(N.SD_TUNE_HALF_TILES, {"auto": -1, "split32": -1, "tiles64": 1}.get(request.param, 0)), "sd_set_tuning")
+    # tiles of 80 / 96 / 112 rows: by the rule ("auto"), that height wherever the layer allows ("rowsNN"), never (the pinned kernels)
+    N.check(lib.sd_set_tuning(N.SD_TUNE_TILE_ROWS, int(request.param[4:]) if request.param.startswith("rows") else (-1 if request.param in ("auto", "split32") else 0)), "sd_set_tuning")
     yield request.param
     N.check(lib.sd_set_tuning(N.SD_TUNE_HALF_TILES, -1), "sd_set_tuning")
+    N.check(lib.sd_set_tuning(N.SD_TUNE_TILE_ROWS, -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_S64_TILES, -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_SKINNY_TILES, -1), "sd_set_tuning")
     N.check(lib.sd_set_tuning(N.SD_TUNE_WIDE_TILES, -1), "sd_set_tuning")
