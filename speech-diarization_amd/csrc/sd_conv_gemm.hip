@@ -878,6 +878,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
   constexpr int NA = TM / 32;                      // staging instructions per wave for the activation rows
   constexpr int PIECES = NA + 2;                   // LDS-DMA pieces per wave and stage
   constexpr int LDCS = S64_T + 4;
+#ifdef SD_STAMP
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = TM == 64 ? wid >> 1 : 0, wn = wid & 1, kh = TM == 64 ? 0 : wid >> 1;
   const int n_tiles = (p.cout + S64_T - 1) / S64_T;
@@ -955,11 +958,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
   for (int s = 0; s < S64_ST - 1; ++s)
     if (s < nk) issue(s);
   int cur = 0;                                     // stage of step kt
+  // Stamped (build_native.py --variant stamp "-DSD_STAMP", tools/stamp_s64.py) at 32 segments, 202 lone workgroups: a K step takes 1570-1700
+  // cycles for 1024 of MFMA, and that did not move with the fragment reads of step kt + 1 issued in front of the MFMAs of kt, with two
+  // accumulator chains, with eight stages (112 KB in flight) or with the pieces issued one by one between MFMA groups (17.1 us per launch
+  // -> 17.1 / 17.2 / 18.3 / 21.4); two workgroups on a CU (64 segments) take 2190 cycles for a step each.
+#ifdef SD_STAMP
+  const unsigned long long t_issued = __builtin_amdgcn_s_memtime();
+  unsigned long long t_first = 0;
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's pieces of step kt have landed: S64_ST - 2 later steps may stay in flight
     if (kt + S64_ST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (S64_ST - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                               // everyone's have, and step kt - 1's stage has been read by every wave
+#ifdef SD_STAMP
+    if (kt == 0) t_first = __builtin_amdgcn_s_memtime();
+#endif
     if (kt + S64_ST - 1 < nk) issue(cur == 0 ? S64_ST - 1 : cur - 1);
     const float* a = smem + cur * STAGE + a_off;
     const float* b = smem + cur * STAGE + b_off;
@@ -976,6 +990,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
     cur = cur == S64_ST - 1 ? 0 : cur + 1;
   }
   __syncthreads();                                 // the ring is free: the C tile goes over it
+#ifdef SD_STAMP
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
   float* Cs = smem;
   {
     const int cl = wn * 32 + (lane & 31), hrow = (lane >> 5) * 4;
@@ -991,7 +1008,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
     }
     __syncthreads();
   }
+#ifdef SD_STAMP
+  const unsigned long long t_cs = __builtin_amdgcn_s_memtime();
+#endif
   sd_store_tile<float, TM, S64_T, 256, 2, 0>(p, Cs, LDCS, m0, n0, tid, vec);
+#ifdef SD_STAMP
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long t_st = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0);                   // stores acknowledged
+  if (tid == 0 && blockIdx.x < 8192) {             // (the 128x128 kernel's buffer: tools/stamp_s64.py)
+    unsigned long long* o = sd_c32_stamp_buf + blockIdx.x * 10;
+    o[0] = t_issued - t_begin;                     // arguments, addresses, first three stages requested
+    o[1] = t_first - t_issued;                     // first stage landed for every wave
+    o[2] = t_loop - t_first;                       // K loop
+    o[3] = t_cs - t_loop;                          // accumulators -> C tile (+ the halves' add)
+    o[4] = t_st - t_cs;                            // parameters, tee_add rows, LDS reads, store issue
+    o[5] = __builtin_amdgcn_s_memtime() - t_st;    // stores retired
+    o[9] = t_begin;
+  }
+#endif
 }
 
 }  // namespace
