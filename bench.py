@@ -126,6 +126,47 @@ def load_traffic():
     return load_profile_json("traffic.json")
 
 
+def reference_batches(state_dict, dev, precision):
+    """The hot path the way the reference itself calls it (never `value`): `ecapa_encode_batch(numpy [B, 32000]) -> numpy` at its batches of 32
+    [REF anti_stick_diarize.py:134] and 128 [REF anti_stick_diarize.py:398] (pageable host memory in, H2D, fbank + ECAPA, D2H, a synchronisation
+    per call), and BASELINE configs[3]'s 16-channel 250 ms hop through `StreamingEmbedder` (hipGraph replay).  Medians after a warm-up."""
+    import time
+    from speech_diarization_amd import speech_encode, synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    from speech_diarization_amd.streaming import StreamingEmbedder
+    out = {"precision": precision}
+    speech_encode.set_precision(precision)
+    for batch, warm, reps in ((32, 80, 80), (128, 30, 30)):
+        wavs = synth.synthetic_segments(5, batch, 32000)
+        for _ in range(warm):
+            speech_encode.ecapa_encode_batch(wavs)
+        lat = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            speech_encode.ecapa_encode_batch(wavs)
+            lat.append(time.perf_counter() - t0)
+        med = float(np.median(lat))
+        out[f"numpy_batch{batch}_segments_per_s"] = batch / med
+        out[f"numpy_batch{batch}_ms_per_call"] = med * 1e3
+    eng = EmbeddingEngine(state_dict, dev, max_batch=16, precision=precision)
+    st = StreamingEmbedder(eng, channels=16, window_s=2.0, hop_s=0.25, use_graph=True)
+    chunk = torch.randn(16, 4000, device=dev) * 0.1
+    for _ in range(20):
+        st.push(chunk)
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(100):
+        t0 = time.perf_counter()
+        st.push(chunk)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    out["stream_16ch_hop_p50_ms"] = float(np.percentile(lat, 50))
+    out["stream_16ch_hop_p99_ms"] = float(np.percentile(lat, 99))
+    out["note"] = ("the reference's own call sizes, outside the timed region and never `value`: numpy in -> numpy out per call at batch 32 / 128, "
+                   "and configs[3]'s 16-channel hop (2 s window every 250 ms) as one graph replay")
+    return out
+
+
 def der_vs_cpu(state_dict, dev, precision):
     """The metric's second half (BASELINE.json: "...; DER vs CPU ref"; BASELINE.md §3: label agreement after clustering,
     DER of the GPU RTTM against the CPU RTTM): BASELINE.json configs[0]'s recording (60 s, 2 synthetic speakers, seed 0)
@@ -444,6 +485,7 @@ def main():
                                                emb16 if extra_f16 is not None else (emb if args.precision == "f16" else None))
             if extra_split is not None and "max_cosine_distance_vs_gpu" in out["cpu_baseline"]:
                 out["cpu_baseline"]["note_split16x3"] = "the f32-split16x3 embeddings sit max_cosine_distance_vs_f32_path from the exact-f32 ones"
+            out["reference_batches"] = reference_batches(state_dict, dev, args.precision)
             out["der"] = der_vs_cpu(state_dict, dev, args.precision)
             out["der_vs_cpu"] = out["der"]["der_vs_cpu"]
             out["labels_identical"] = out["der"]["labels_identical"]
