@@ -961,7 +961,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_s64_kernel(const sd_conv
   // Stamped (build_native.py --variant stamp "-DSD_STAMP", tools/stamp_s64.py) at 32 segments, 202 lone workgroups: a K step takes 1570-1700
   // cycles for 1024 of MFMA, and that did not move with the fragment reads of step kt + 1 issued in front of the MFMAs of kt, with two
   // accumulator chains, with eight stages (112 KB in flight) or with the pieces issued one by one between MFMA groups (17.1 us per launch
-  // -> 17.1 / 17.2 / 18.3 / 21.4); two workgroups on a CU (64 segments) take 2190 cycles for a step each.
+  // -> 17.1 / 17.2 / 18.3 / 21.4); two workgroups on a CU (64 segments) take 2190 cycles for a step each.  1570 cycles is the step's 16 KB at
+  // ~10.4 B per cycle: what one CU gets of data from beyond its XCD's L2 (fbank's load phase: ~11).
 #ifdef SD_STAMP
   const unsigned long long t_issued = __builtin_amdgcn_s_memtime();
   unsigned long long t_first = 0;
