@@ -62,6 +62,34 @@ def test_config1_full_size_properties(dev):
     print(f"config 1 full size: f16 vs f32 max cosine distance {float(cos16.max()):.2e}, vs float64 oracle {cd.max():.2e}")
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_reference_batch_sizes_agree_with_a_small_batch_and_the_oracle(dev, precision):
+    """The reference's own call sizes (16-segment hop, batches of 32 [REF anti_stick_diarize.py:134] and 128 [REF anti_stick_diarize.py:398]) and
+    the sizes between them send the layers to different kernels (32x64 / 64x64 ring tiles, 80 / 96 / 112-row and 128x64 tiles, grid split-K for
+    the per-segment layers, 256 / 512 pooling channels per workgroup): a segment's embedding must not depend on the batch it sits in beyond f32
+    rounding, the same call twice is bitwise equal, and six of the rows are held against the float64 oracle."""
+    from oracle import pipeline_ref
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234)
+    wav_np = synth.synthetic_segments(3, 300, 32000)
+    wav = torch.from_numpy(wav_np).to(dev)
+    eng = EmbeddingEngine(sd, dev, max_batch=512, precision=precision)
+    pick = [0, 1, 7, 15, 150, 299]
+    small = eng.embed(wav[pick])
+    tol = 1e-9 if precision == "f32" else 2e-4
+    for B in (16, 24, 32, 48, 64, 100, 128, 256, 257, 300):
+        emb = eng.embed(wav[:B])
+        assert torch.equal(emb, eng.embed(wav[:B])), B
+        rows = [i for i, r in enumerate(pick) if r < B]
+        cos = 1.0 - torch.nn.functional.cosine_similarity(emb[[pick[i] for i in rows]].double(), small[rows].double(), dim=1)
+        assert float(cos.max()) < tol, (B, float(cos.max()))
+    ref = pipeline_ref.encode_batch_ref(sd, wav_np[pick], torch.float64)
+    e = small.cpu().numpy().astype(np.float64)
+    cd = 1.0 - (e * ref).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(ref, axis=1))
+    assert cd.max() < (1e-5 if precision == "f32" else 1e-3), cd
+
+
 @pytest.mark.parametrize("precision", ["f32", "f32s"])
 def test_config1_at_the_bench_launch_shape(dev, precision):
     """`bench.py`'s step since round 3: ONE forward of 10 000 segments (max_batch = micro-batch = 10 000; ~105 GB of
