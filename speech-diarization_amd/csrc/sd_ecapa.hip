@@ -235,6 +235,9 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   const bool split = w->split16 != 0 && dt == SD_DT_F32;
   const bool wsplit = w->split16 == 1 && dt == SD_DT_F32;
   const long nt = sd_f16_narrow_tiles().load(std::memory_order_relaxed);      // one snapshot per forward
+  // rows per unit of the column statistics, for sizing them: the exact-f32 operator may pick tiles of 80 / 96 / 112 rows (small launches);
+  // the f16 and split kernels always write units of 128
+  const size_t stat_unit = (dt == SD_DT_F32 && !wsplit) ? 80 : 128;
 
   static const bool colstat_ok = [] {     // SD_COLSTAT=0: A/B switch for measurements
     const char* e = sd_experiment_env("SD_COLSTAT");
@@ -309,9 +312,8 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
     // geometry allows (the Res2Net scratch s0 is dead and holds them), else from a pass over t2
     {
       sd_conv_args a = conv_of(blk.tdnn2, b.r, dt, C, 0, b.t2, dt, C, 0, M, T, SD_ACT_RELU);
-      // (units of 80 rows, the smallest tile of the exact-f32 operator, bound the size of the statistics)
       const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && C % 256 == 0 && !(wsplit && blk.tdnn2.w_split && wide_goes_narrow(blk.tdnn2, M, nt)) &&
-                        (size_t)((M + 79) / 80) * 6 * C * sizeof(float) <= (size_t)M * chunk * es;
+                        (size_t)((M + stat_unit - 1) / stat_unit) * 6 * C * sizeof(float) <= (size_t)M * chunk * es;
       if (stat) a.colstat = static_cast<float*>(b.s0);
       int rows = 128;
       SD_TRY(run_wide(blk.tdnn2, a, wsplit, b.xs, nt, stream, r_split ? b.rs : nullptr, C, stat ? &rows : nullptr));
@@ -348,7 +350,7 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   {
     sd_conv_args a = conv_of(w->mfa, b.xcat, dt, Cm, 0, b.h, dt, Cm, 0, M, T, SD_ACT_RELU);
     const bool stat = colstat_ok && T >= (wsplit ? 128 : 64) && Cm % 256 == 0 && !(wsplit && w->mfa.w_split && wide_goes_narrow(w->mfa, M, nt)) &&
-                      (size_t)((M + 79) / 80) * 6 * Cm * sizeof(float) <= (size_t)M * C * es;
+                      (size_t)((M + stat_unit - 1) / stat_unit) * 6 * Cm * sizeof(float) <= (size_t)M * C * es;
     if (stat) a.colstat = static_cast<float*>(b.r);
     int rows = 128;
     SD_TRY(run_wide(w->mfa, a, wsplit, b.xs, nt, stream, b.xcs, Cm, stat ? &rows : nullptr));
