@@ -35,12 +35,13 @@ __device__ __forceinline__ void st4(_Float16* p, f32x4 v) {
 }
 
 // part[RP][CG] reduction helper: returns the fixed-order sum over row phases (valid for rp == 0)
+template <int CGv = CG, int RPv = RP>
 __device__ __forceinline__ f32x4 combine_sum(f32x4* part, int rp, int cg, f32x4 v) {
-  part[rp * CG + cg] = v;
+  part[rp * CGv + cg] = v;
   __syncthreads();
   f32x4 s = part[cg];
 #pragma unroll
-  for (int k = 1; k < RP; ++k) s += part[k * CG + cg];
+  for (int k = 1; k < RPv; ++k) s += part[k * CGv + cg];
   __syncthreads();
   return s;
 }
@@ -58,19 +59,22 @@ __device__ __forceinline__ f32x4 combine_max(f32x4* part, int rp, int cg, f32x4 
   return s;
 }
 
-template <typename T>
+// CGv channel groups (of 4) x RPv row phases = 256 threads: 64 x 4 (a thread walks a quarter of the segment's rows) for launches that fill the
+// chip, 16 x 16 for the few segments of a small batch (16 segments x 1024 channels: 64 workgroups of 50 dependent steps each took 15-17 us)
+template <typename T, int CGv = CG, int RPv = RP>
 __global__ __launch_bounds__(256) void seg_mean_std_kernel(const T* x, int ld, int col0, int Tn, int C,
                                                            int want_std, float eps, float* out) {
-  __shared__ f32x4 part[RP * CG];
+  static_assert(CGv * RPv == 256, "one workgroup");
+  __shared__ f32x4 part[RPv * CGv];
   const int b = blockIdx.y;
-  const int cg = threadIdx.x & (CG - 1), rp = threadIdx.x >> 6;
-  const int c = (blockIdx.x * CG + cg) * 4;
+  const int cg = threadIdx.x % CGv, rp = threadIdx.x / CGv;
+  const int c = (blockIdx.x * CGv + cg) * 4;
   const bool ok = c < C;
   const T* base = x + (size_t)b * Tn * ld + col0 + (ok ? c : 0);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (ok)
-    for (int t = rp; t < Tn; t += RP) s += ld4(base + (size_t)t * ld);
-  s = combine_sum(part, rp, cg, s);
+    for (int t = rp; t < Tn; t += RPv) s += ld4(base + (size_t)t * ld);
+  s = combine_sum<CGv, RPv>(part, rp, cg, s);
   const float invT = 1.0f / (float)Tn;
   const f32x4 mean = s * invT;
   const int ostride = want_std ? 2 * C : C;
@@ -78,11 +82,11 @@ __global__ __launch_bounds__(256) void seg_mean_std_kernel(const T* x, int ld, i
   if (!want_std) return;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (ok)
-    for (int t = rp; t < Tn; t += RP) {
+    for (int t = rp; t < Tn; t += RPv) {
       const f32x4 d = ld4(base + (size_t)t * ld) - mean;
       v += d * d;
     }
-  v = combine_sum(part, rp, cg, v);
+  v = combine_sum<CGv, RPv>(part, rp, cg, v);
   if (ok && rp == 0) {
     f32x4 sd;
 #pragma unroll
@@ -407,7 +411,13 @@ extern "C" int sd_seg_mean_std_dt(const void* x, int x_dtype, int ld, int col0, 
   SD_CHECK_ARG(B > 0 && T > 0 && out && sd_aligned16(out), "sd_seg_mean_std_dt: B=%d T=%d / null or unaligned output", B, T);
   dim3 grid((C / 4 + CG - 1) / CG, B);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (x_dtype == SD_DT_F16)
+  if ((long)grid.x * B < 256) {           // a small batch: 16 channel groups x 16 row phases per workgroup
+    dim3 g16((C / 4 + 15) / 16, B);
+    if (x_dtype == SD_DT_F16)
+      hipLaunchKernelGGL((seg_mean_std_kernel<_Float16, 16, 16>), g16, dim3(256), 0, s, static_cast<const _Float16*>(x), ld, col0, T, C, want_std, eps, out);
+    else
+      hipLaunchKernelGGL((seg_mean_std_kernel<float, 16, 16>), g16, dim3(256), 0, s, static_cast<const float*>(x), ld, col0, T, C, want_std, eps, out);
+  } else if (x_dtype == SD_DT_F16)
     hipLaunchKernelGGL(seg_mean_std_kernel<_Float16>, grid, dim3(256), 0, s, static_cast<const _Float16*>(x), ld, col0, T, C, want_std, eps, out);
   else
     hipLaunchKernelGGL(seg_mean_std_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(x), ld, col0, T, C, want_std, eps, out);
