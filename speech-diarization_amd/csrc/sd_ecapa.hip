@@ -146,8 +146,13 @@ int run_conv(const sd_conv_args& a, sd_stream_t stream, int* stat_rows = nullptr
 // products per value pair; otherwise the exact-f32 kernel.
 // A narrow layer of the f32 schedule (Res2Net convs, attention TDNN): in split16 mode, when it carries the second packing, the
 // 128x128 split kernel (f32 activations split while staged; tee / tee_add / per-segment bias as in the exact kernel).
+// Small launches (at most 56 tiles of 128x128: up to ~35 two-second segments) stay on the exact-f32 operator, whose ring kernel spreads
+// them over 64x64 / 32x64 tiles: measured per launch at 16 / 32 segments, Res2Net conv 9.5 / 14.3 us exact against 17.7 / 19.0 split (26 / 51
+// workgroups of 128x128), attention TDNN 49 / 76 against 105 / 110; at 64 segments the split kernel is ahead again.
 int run_narrow(const sd_layer& l, sd_conv_args a, bool split, sd_stream_t stream) {
-  if (!(split && l.w_split && !l.bias_split && a.x_dtype == SD_DT_F32 && !a.colstat)) {
+  const long tiles128 = (long)((a.M + 127) / 128) * ((a.cout + 127) / 128);
+  const bool small = a.T > 1 && tiles128 <= 56 && a.y_dtype != SD_DT_SPLIT16 && l.w != nullptr && l.w_dtype == SD_DT_F32;
+  if (small || !(split && l.w_split && !l.bias_split && a.x_dtype == SD_DT_F32 && !a.colstat)) {
     if (a.y_dtype == SD_DT_SPLIT16) return sd_set_error(SD_ERR_UNSUPPORTED, "sd_ecapa_forward: a split output needs the split narrow kernel");
     return run_conv(a, stream);
   }
