@@ -491,7 +491,8 @@ extern "C" int sd_colstat_finish_dt(const float* colstat, const float* pivot, co
 int sd_colstat_finish_rows(const float* colstat, const float* pivot, const void* y, int y_dtype, int ldy, int y_col0,
                            int B, int T, int C, int want_std, float eps, float* out, int unit_rows, sd_stream_t stream) {
   SD_CHECK_ARG(colstat && y && out, "sd_colstat_finish_dt: null pointer");
-  SD_CHECK_ARG(unit_rows > 0 && unit_rows <= 128 && 2 * T >= unit_rows, "sd_colstat_finish: unit of %d rows with T=%d", unit_rows, T);
+  // (units of 80 rows carry two parts per tile, the others three: sd_conv_gemm.hip)
+  SD_CHECK_ARG(unit_rows > 0 && unit_rows <= 128 && (unit_rows == 80 ? T >= 80 : 2 * T >= unit_rows), "sd_colstat_finish: unit of %d rows with T=%d", unit_rows, T);
   SD_CHECK_ARG(y_dtype == SD_DT_F32 || y_dtype == SD_DT_F16, "sd_colstat_finish_dt: y_dtype=%d", y_dtype);
   SD_CHECK_ARG(B >= 0 && T >= 64 && C > 0, "sd_colstat_finish_dt: B=%d T=%d (>= 64) C=%d", B, T, C);
   SD_CHECK_ARG((long)B * T < (1L << 31) && y_col0 >= 0 && y_col0 + C <= ldy, "sd_colstat_finish_dt: bad shape");
