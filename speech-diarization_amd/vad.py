@@ -142,8 +142,15 @@ def mask_to_segments(mask: np.ndarray, hop_ms: float, min_speech_ms: float = 250
     opens = np.concatenate(([True], (starts[1:] - ends[:-1]) > max_gap))
     seg_start = starts[opens]
     seg_end = ends[np.concatenate((np.flatnonzero(opens)[1:] - 1, [starts.size - 1]))]
+    # Two rounding regimes [REF vad.py:157-160]: frame indices are numpy integers there, so `index * hop_s` is a numpy
+    # float and round() is numpy's scale / rint / unscale -- except for an end that the clamp replaces by len(mask), a
+    # Python int, whose product is a Python float rounded correctly to 3 decimals.  The two differ on ties of the
+    # scaled value (hop 12.5 ms: 361 * 0.0125 -> 4.513 by Python's round, 4.512 by numpy's).
     s = np.round(np.maximum(seg_start - pad, 0) * hop_s, 3)
-    e = np.round(np.minimum(seg_end + pad, total) * hop_s, 3)
+    e_pad = seg_end + pad
+    e = np.round(np.minimum(e_pad, total) * hop_s, 3)
+    if e_pad[-1] > total:
+        e[e_pad > total] = round(total * hop_s, 3)
     return [(float(a), float(b)) for a, b in zip(s, e)]
 
 

@@ -135,6 +135,34 @@ def main():
         tracks.append(dict(probs=[float(v) for v in probs], variants=variants))
     out["vad"] = tracks
 
+    # ---- the same functions off the default hop: the reference rounds an end that its clamp replaced by len(mask)
+    # (a Python int) with Python's round and everything else with numpy's [REF vad.py:157-160]; the two differ on ties,
+    # which hop 10 ms never produces.  Masks are random runs; `tail` forces the last run to reach (or stop short of) the end.
+    hops = []
+    rng = np.random.default_rng(20250)
+    for hop_ms in [2.5, 7.5, 10.0, 12.5, 16.0, 20.0]:
+        cases = []
+        for k in range(60):
+            n = int(rng.integers(20, 900))
+            m = np.zeros(n, bool)
+            pos = int(rng.integers(0, 30))
+            while pos < n:
+                run = int(rng.integers(1, 120))
+                m[pos:pos + run] = True
+                pos += run + int(rng.integers(1, 60))
+            tail = k % 3
+            if tail == 0:
+                m[n - int(rng.integers(1, 40)):] = True        # the last run touches the end: any pad is clamped
+            elif tail == 1:
+                m[n - int(rng.integers(1, 12)):] = False       # ends a few frames short: clamped only by the larger pads
+            min_speech, min_gap = [(250.0, 100.0), (25.0, 5.0), (150.0, 250.0)][k % 3]
+            m2 = rvad.morph_open_close(m, hop_ms, 80.0, 40.0) if k % 2 else m
+            segs = [dict(speech_pad_ms=pad, segments=rvad.mask_to_segments(m2, hop_ms, min_speech, min_gap, pad))
+                    for pad in [0.0, 12.5, 40.0, 80.0]]
+            cases.append(dict(mask=bits(m), morphed=bool(k % 2), mask2=bits(m2) if k % 2 else None, min_speech_ms=min_speech, min_gap_ms=min_gap, pads=segs))
+        hops.append(dict(hop_ms=hop_ms, cases=cases))
+    out["vad_hops"] = hops
+
     # ---- diarization_baseline glue
     db = []
     for seed in range(12):

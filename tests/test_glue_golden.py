@@ -335,3 +335,37 @@ def test_diarize_accepts_the_reference_call_forms(tmp_path):
     assert np.array_equal(got["y"], m)
     with pytest.raises(ImportError):
         asd.loudness_normalize(m, 16000)
+
+
+def test_vad_off_the_default_hop_matches_reference(golden_dir):
+    """hop_ms in {2.5, 7.5, 10, 12.5, 16, 20} x pads {0, 12.5, 40, 80} x ends that are / are not clamped to len(mask):
+    the reference rounds a clamped end with Python's round and every other time with numpy's [REF vad.py:157-160]."""
+    n_cases = n_clamped = 0
+    for h in _load(golden_dir, "vad_hops"):
+        hop_ms = h["hop_ms"]
+        for c in h["cases"]:
+            m = _bits(c["mask"])
+            m2 = m
+            if c["morphed"]:
+                m2 = vad.morph_open_close(m, hop_ms, 80.0, 40.0)
+                assert np.array_equal(m2, _bits(c["mask2"])), hop_ms
+            for p in c["pads"]:
+                got = vad.mask_to_segments(m2, hop_ms, c["min_speech_ms"], c["min_gap_ms"], p["speech_pad_ms"])
+                assert got == _pairs(p["segments"]), (hop_ms, p["speech_pad_ms"], c["mask"])
+                n_cases += 1
+                n_clamped += bool(got) and got[-1][1] == round(len(m2) * hop_ms / 1000.0, 3)
+    assert n_cases >= 1400 and n_clamped >= 300
+
+
+def test_mask_to_segments_tie_cases_the_two_roundings_disagree_on():
+    # 361 frames of 12.5 ms: 361 * 0.0125 = 4.5125 exactly-ish; Python's round gives 4.513, numpy's 4.512.  The reference
+    # uses the former only when the end was clamped to len(mask) [REF vad.py:158-160].
+    m = np.zeros(361, bool)
+    m[300:361] = True
+    assert vad.mask_to_segments(m, 12.5, 25.0, 5.0, 40.0)[-1][1] == 4.513       # clamped: Python round
+    m = np.zeros(400, bool)
+    m[300:361] = True
+    assert vad.mask_to_segments(m, 12.5, 25.0, 5.0, 0.0)[-1][1] == 4.512        # not clamped: numpy round
+    m = np.zeros(361, bool)
+    m[300:361] = True
+    assert vad.mask_to_segments(m, 12.5, 25.0, 5.0, 0.0)[-1][1] == 4.512        # e + pad == total: min() keeps the numpy int
