@@ -24,7 +24,6 @@ Known defects of the reference that this module does NOT reproduce by default
 from __future__ import annotations
 
 import math
-import warnings
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Callable
@@ -50,24 +49,29 @@ class Segment:
 
 def loudness_normalize(y: np.ndarray, sr: int, target_lufs: float = -18.0) -> np.ndarray:
     """Integrated-loudness normalisation to `target_lufs`, clipped to +-0.99 [REF anti_stick_diarize.py:53-61].  The meter
-    is the reference's own dependency (`pyloudnorm`, ITU-R BS.1770); it is not restated here: without it this raises."""
-    import pyloudnorm as pyln
-    meter = pyln.Meter(sr)
-    y = pyln.normalize.loudness(y, meter.integrated_loudness(y), target_lufs)
+    is the reference's own dependency when it is installed (`pyloudnorm`, ITU-R BS.1770) and the restatement of its
+    algorithm in `loudness.py` otherwise -- the step is never skipped: the reference applies it unconditionally, and
+    VAD thresholds, SCD and the encoder all see the gain and the clip.  Only the absence of the `pyloudnorm` package
+    itself selects the restatement; an ImportError from inside it (say a missing scipy) propagates."""
+    try:
+        import pyloudnorm as pyln
+    except ModuleNotFoundError as e:
+        if e.name != "pyloudnorm":
+            raise
+        from . import loudness
+        y = loudness.normalize_loudness(y, loudness.Meter(sr).integrated_loudness(y), target_lufs)
+    else:
+        y = pyln.normalize.loudness(y, pyln.Meter(sr).integrated_loudness(y), target_lufs)
     return np.clip(y, -0.99, 0.99)
-
-
-_warned_no_meter = False
 
 
 def diar_read_audio(path_wav, sr: int = 16000, lufs: float | None = -18.0):
     """-> (conditioned mono float32 signal, sr) [REF anti_stick_diarize.py:29-50]: a path is read and resampled
     (`audio_io.read_audio`: WAV; polyphase resampling where the reference uses librosa's kaiser_fast), an
     `(array, orig_sr)` tuple is transposed when it is [n, <= 2], resampled and mixed down; then loudness normalisation
-    when `lufs` is not None AND a loudness meter is importable (otherwise the `lufs=None` behaviour, with ONE warning per
-    process), DC removal, and pre-emphasis 0.97 with librosa's initial state (`zi = 2 x[0] - x[1]` handed to `lfilter`
+    when `lufs` is not None (always: `loudness_normalize` carries its own BS.1770 meter for hosts without pyloudnorm;
+    pass `lufs=None` to opt out, as in the reference), DC removal, and pre-emphasis 0.97 with librosa's initial state (`zi = 2 x[0] - x[1]` handed to `lfilter`
     as it is [UPSTREAM-RECALLED librosa.effects.preemphasis], i.e. y[0] = 3 x[0] - x[1], y[n] = x[n] - 0.97 x[n-1])."""
-    global _warned_no_meter
     from . import audio_io
     if isinstance(path_wav, (str, Path)):
         wav, sr = audio_io.read_audio(path_wav, sr=sr, mono=True)
@@ -83,13 +87,7 @@ def diar_read_audio(path_wav, sr: int = 16000, lufs: float | None = -18.0):
         if wav.ndim == 2:
             wav = wav.mean(axis=0)
     if lufs is not None:
-        try:
-            wav = loudness_normalize(wav, sr, target_lufs=lufs)
-        except ImportError:
-            if not _warned_no_meter:
-                _warned_no_meter = True
-                warnings.warn("pyloudnorm is not installed: target_lufs is ignored (signal conditioned as with target_lufs=None)",
-                              RuntimeWarning, stacklevel=2)
+        wav = loudness_normalize(wav, sr, target_lufs=lufs)
     wav = np.asarray(wav, dtype=np.float32)
     if wav.size == 0:
         return wav, sr

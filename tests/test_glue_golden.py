@@ -295,23 +295,25 @@ def test_diarize_with_a_single_segment_returns_one_speaker():
 
 def test_diarize_accepts_the_reference_call_forms(tmp_path):
     """[REF anti_stick_diarize.py:493-512]: first argument a path or an (array, sr) tuple, `target_lufs` third; the
-    loaded signal is conditioned by `diar_read_audio` (DC removal + 0.97 pre-emphasis; no loudness meter in this
-    image: one warning, `target_lufs=None` behaviour).  A bare array is taken as already conditioned."""
-    import warnings
+    loaded signal is conditioned by `diar_read_audio` (loudness normalisation unless `lufs=None`, DC removal, 0.97
+    pre-emphasis).  A bare array is taken as already conditioned."""
     from scipy.signal import lfilter
     from speech_diarization_amd import audio_io
     rng = np.random.default_rng(1)
     x48 = (0.1 * rng.standard_normal((48000 * 2, 2)) + 0.02).astype(np.float32)        # [n, 2] at 48 kHz with a DC offset
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
-        y, sr = asd.diar_read_audio((x48, 48000), 16000, lufs=-18.0)
-        y_none, _ = asd.diar_read_audio((x48, 48000), 16000, lufs=None)
-    assert sr == 16000 and y.dtype == np.float32 and y.shape == (32000,) and np.array_equal(y, y_none)
+    y, sr = asd.diar_read_audio((x48, 48000), 16000, lufs=None)
+    assert sr == 16000 and y.dtype == np.float32 and y.shape == (32000,)
     from scipy.signal import resample_poly
-    m = resample_poly(x48.T, 1, 3, axis=-1).astype(np.float32).mean(axis=0)
-    m = m - m.mean()
+    m0 = resample_poly(x48.T, 1, 3, axis=-1).astype(np.float32).mean(axis=0)
+    m = m0 - m0.mean()
     want = lfilter([1.0, -0.97], [1.0], m.astype(np.float64), zi=[2.0 * m[0] - m[1]])[0]      # librosa's preemphasis
     assert np.abs(y - want).max() < 1e-6
+    # lufs given: the gain and the +-0.99 clip are applied BEFORE DC removal and pre-emphasis [REF :44-49], never skipped
+    y18, _ = asd.diar_read_audio((x48, 48000), 16000, lufs=-18.0)
+    g = asd.loudness_normalize(m0, 16000, -18.0)
+    assert np.abs(g).max() <= 0.99 and not np.allclose(g, m0)
+    g = g.astype(np.float32) - g.astype(np.float32).mean()
+    assert np.abs(y18[1:] - (g[1:] - np.float32(0.97) * g[:-1])).max() < 1e-6
     assert asd.diar_read_audio((np.zeros(0, np.float32), 16000), lufs=None)[0].size == 0
     wav = tmp_path / "a.wav"
     audio_io.write_wav16(wav, m, 16000)
@@ -321,20 +323,51 @@ def test_diarize_accepts_the_reference_call_forms(tmp_path):
         got["y"], got["kw"] = sig, kw
         return []
 
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
-        assert asd.diarize(str(wav), 16000, -18.0, 0.7, 0.3, vad_segments=vad_segments) == []
+    assert asd.diarize(str(wav), 16000, None, 0.7, 0.3, vad_segments=vad_segments) == []
     assert got["kw"]["on_threshold"] == 0.7 and got["kw"]["off_threshold"] == 0.3          # positional slots 4 and 5, as in the reference
     assert got["y"].shape == (32000,) and abs(float(got["y"][5:].mean())) < 1e-3
     p = np.round(m * 32767.0).clip(-32768, 32767) / 32768.0
     p = p - p.mean()
     assert np.abs(got["y"][1:] - (p[1:] - 0.97 * p[:-1])).max() < 1e-5                     # read from the file, then conditioned
+    asd.diarize(str(wav), 16000, -18.0, 0.7, 0.3, vad_segments=vad_segments)               # target_lufs third: a different signal
+    assert np.abs(got["y"][1:] - (p[1:] - 0.97 * p[:-1])).max() > 1e-3
     asd.diarize((m, 16000), vad_segments=vad_segments, target_lufs=None)
     assert np.abs(got["y"][1:] - (m[1:] - np.float32(0.97) * m[:-1])).max() < 1e-6
     asd.diarize(m, vad_segments=vad_segments)                                              # bare array: untouched
     assert np.array_equal(got["y"], m)
-    with pytest.raises(ImportError):
-        asd.loudness_normalize(m, 16000)
+
+
+def test_loudness_normalize_meter(monkeypatch):
+    """[REF anti_stick_diarize.py:53-61] BS.1770 integrated loudness -> one gain -> clip to +-0.99.  Known answers of the
+    standard: a full-scale 997 Hz sine reads -3.01 LKFS per channel (0.0 as identical stereo), loudness follows the gain
+    dB for dB, silence in front of the programme is gated away.  The meter is pyloudnorm when importable, `loudness.py`
+    otherwise; an ImportError from INSIDE pyloudnorm is not taken for its absence."""
+    import builtins
+    from speech_diarization_amd import loudness
+    sr = 16000
+    tone = np.sin(2 * np.pi * 997.0 * np.arange(5 * sr) / sr)
+    m = loudness.Meter(sr)
+    assert abs(m.integrated_loudness(tone) + 3.01) < 0.1
+    assert abs(m.integrated_loudness(0.1 * tone) - (m.integrated_loudness(tone) - 20.0)) < 1e-9
+    assert abs(m.integrated_loudness(np.stack([tone, tone], axis=1))) < 0.1
+    assert abs(loudness.Meter(48000).integrated_loudness(np.sin(2 * np.pi * 997.0 * np.arange(5 * 48000) / 48000)) + 3.01) < 0.05
+    gated = np.concatenate([np.zeros(5 * sr), 0.1 * tone])
+    assert abs(m.integrated_loudness(gated) - m.integrated_loudness(0.1 * tone)) < 0.3
+    with pytest.raises(ValueError):
+        m.integrated_loudness(tone[:1000])                                                 # shorter than one 400 ms block
+    out = asd.loudness_normalize(0.01 * tone, sr, -18.0)
+    assert abs(m.integrated_loudness(out) + 18.0) < 1e-6 and np.abs(out).max() <= 0.99
+    assert np.abs(asd.loudness_normalize(tone, sr, 0.0)).max() == 0.99                     # +3 dB on a full-scale tone: clipped
+    real_import = builtins.__import__
+
+    def broken(name, *a, **k):
+        if name == "pyloudnorm":
+            raise ModuleNotFoundError("No module named 'scipy.somewhere'", name="scipy.somewhere")
+        return real_import(name, *a, **k)
+
+    monkeypatch.setattr(builtins, "__import__", broken)
+    with pytest.raises(ModuleNotFoundError):
+        asd.loudness_normalize(tone, sr)
 
 
 def test_vad_off_the_default_hop_matches_reference(golden_dir):
