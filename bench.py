@@ -244,8 +244,9 @@ def main():
     engine = EmbeddingEngine(state_dict, dev, max_batch=args.micro_batch, precision=args.precision)
     S = args.segments
     # generated on the device by the counter-based generator, seed 0, N(0, 0.1^2) clipped to
-    # [-1, 1]; rank r owns rows [r S, (r + 1) S) of the one stream
-    wav = synth.synthetic_segments_device(0, S, SAMPLES, dev, std=0.1, first_row=rank * S)
+    # [-1, 1]; ONE stream of S * world segments, sharded round-robin as SURVEY §8(e) / dist.shard_indices say: rank r owns
+    # rows r, r + W, r + 2 W, ...  (so the de-interleaved all-gather is the stream in its original order)
+    wav = synth.synthetic_segments_device(0, S, SAMPLES, dev, std=0.1, first_row=rank, row_stride=world)
     n_total = S * world
     lo, hi = sdist.row_block(n_total, rank, world)
     aff = torch.empty((hi - lo, n_total), dtype=torch.float32, device=dev)
@@ -257,21 +258,31 @@ def main():
         torch.cuda.synchronize()
 
     aff_ms = [0.0]          # average duration of one affinity call (l2norm + tiled product) of the last measure()
+    gather = {}             # the exchange step of the last measure(): event-timed like the affinity
 
     def measure(eng):
         """W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
-        aff_events = []
+        aff_events, ag_events = [], []
+        last = {}
 
         def step(timed=False):
             emb = eng.embed(wav)
+            # the collective is enqueued behind the forward on torch's current stream (RCCL's own stream waits for it and
+            # the current stream waits for RCCL's): an event pair on the current stream brackets pad + all-gather + de-interleave
+            if timed:
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
             full = sdist.all_gather_embeddings(emb, n_total)
-            if timed:       # the affinity runs on torch's current stream: events on that stream bracket its launches
+            if timed:
+                g1.record()
+                ag_events.append((g0, g1))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             ops.cosine_affinity(full, out=aff, rows=(lo, hi))
             if timed:
                 e1.record()
                 aff_events.append((e0, e1))
+            last["full"] = full
             return emb
         for _ in range(args.warmup):
             step()
@@ -283,6 +294,23 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         aff_ms[0] = sum(a.elapsed_time(b) for a, b in aff_events) / max(len(aff_events), 1)
+        ag_ms = sum(a.elapsed_time(b) for a, b in ag_events) / max(len(ag_events), 1)
+        # order of the gathered matrix: row k W + r is rank r's k-th segment, i.e. full[rank::W] are this rank's own embeddings, bitwise
+        full = last["full"]
+        order_ok = bool(torch.equal(full[rank::world], emb)) and tuple(full.shape) == (n_total, emb.shape[1])
+        gather.clear()
+        gather.update({"allgather_ms": ag_ms, "order_ok": order_ok, "dt_local": dt})
+        if world > 1:
+            stats = torch.tensor([dt, ag_ms, 1.0 if order_ok else 0.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            every = [torch.empty_like(stats) for _ in range(world)]
+            dist.all_gather(every, stats)
+            every = torch.stack(every).cpu()
+            gather.update({"ms_per_step_by_rank": [float(v) / args.steps * 1e3 for v in every[:, 0]],
+                           "allgather_ms_by_rank": [float(v) for v in every[:, 1]],
+                           "order_ok": bool((every[:, 2] == 1.0).all())})
+            if not gather["order_ok"]:
+                raise SystemExit("all-gather order check failed: full[rank::world] != this rank's embeddings")
+            gather["full"] = full
         conv = _native.profile_read(_native.SD_PROF_CONV_GEMM)
         wide = _native.profile_read(_native.SD_PROF_CONV_WIDE)
         fb = _native.profile_read(_native.SD_PROF_FBANK)
@@ -297,6 +325,24 @@ def main():
 
     dt, (conv_ms, conv_n, conv_flops), (fb_ms, fb_n, fb_bytes), emb, (wide_ms, wide_n, wide_flops) = measure(engine)
     affinity_ms = aff_ms[0]
+    exchange = dict(gather)         # of the headline measurement (the extra precisions below overwrite `gather`)
+    full_main = exchange.pop("full", None)
+    if world > 1 and rank == 0:
+        # parity of what arrived from the OTHER ranks: rank 0 regenerates the first 16 segments of every other shard from the
+        # one stream, embeds them itself and compares with the rows the collective delivered (a different batch around a
+        # segment regroups its statistics sums: equal to f32 rounding, < 1e-9 cosine, not bitwise; own rows: bitwise, above)
+        k = min(16, S)
+        theirs = torch.cat([synth.synthetic_segments_device(0, k, SAMPLES, dev, std=0.1, first_row=r, row_stride=world) for r in range(1, world)])
+        mine = engine.embed(theirs).double()
+        got = torch.cat([full_main[r::world][:k] for r in range(1, world)]).double()
+        cosd = 1.0 - torch.nn.functional.cosine_similarity(mine, got, dim=1)
+        exchange["gathered_rows_checked"] = int(got.shape[0])
+        exchange["gathered_max_cosine_distance_vs_local_recompute"] = float(cosd.max().item())
+        bar = 1e-9 if args.precision in ("f32", "f32s", "f32ns") else 1e-5
+        if not float(cosd.max().item()) < bar:
+            raise SystemExit(f"gathered embeddings differ from rank 0's recomputation: max cosine distance {float(cosd.max().item()):.3e}")
+        del theirs, mine, got
+    del full_main
     extra_f16 = None
     emb16 = None
     if args.precision == "f32" and not args.no_f16_extra:
@@ -408,6 +454,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "value_per_gpu": value / (world if backend == "nccl" else min(world, n_dev)),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -420,7 +467,7 @@ def main():
                             "cosine affinity of the rank's row block on-device",
                 "segments_per_gpu": S, "samples_per_segment": SAMPLES, "micro_batch": args.micro_batch,
                 "affinity_rows_per_gpu": hi - lo, "affinity_cols": n_total,
-                "parallelism": f"segments sharded over {world} rank(s) on {min(world, n_dev)} GPU(s), one all_gather_into_tensor per step",
+                "parallelism": f"segments sharded round-robin (i mod {world}) over {world} rank(s) on {min(world, n_dev)} GPU(s), one all_gather_into_tensor per step",
                 "gpus_visible": n_dev,
             },
             "roofline": {
@@ -473,6 +520,22 @@ def main():
                     (n_total + 127) // 128, ((((n_total + 127) // 128) + 1) / (2.0 * ((n_total + 127) // 128))) if (a_rows == n_total) else 1.0),
                 "timing": "torch.cuda.Event pairs on the launch stream around every timed call",
             }
+        # the path's ONE exchange step: pad + all_gather_into_tensor of W x ceil(N/W) x 192 f32 + de-interleave
+        emb_bytes = int(world * sdist.shard_rows(n_total, world) * emb.shape[1] * 4)
+        out["allgather"] = {
+            "collective": "all_gather_into_tensor" if world > 1 else "none (world of one: the local embeddings are the gathered matrix)",
+            "allgather_ms": exchange["allgather_ms"], "bytes_received_per_rank": emb_bytes if world > 1 else 0,
+            "allgather_ms_by_rank": exchange.get("allgather_ms_by_rank", [exchange["allgather_ms"]]),
+            "ms_per_step_by_rank": exchange.get("ms_per_step_by_rank", [dt / args.steps * 1e3]),
+            "ms_per_step_min": min(exchange.get("ms_per_step_by_rank", [dt / args.steps * 1e3])),
+            "ms_per_step_max": max(exchange.get("ms_per_step_by_rank", [dt / args.steps * 1e3])),
+            "share_of_step_time": exchange["allgather_ms"] * 1e-3 * args.steps / dt,
+            "order_check": "full[rank::world] == this rank's embeddings, bitwise, on every rank" if exchange["order_ok"] else "FAILED",
+            "gathered_rows_checked": exchange.get("gathered_rows_checked", 0),
+            "gathered_max_cosine_distance_vs_local_recompute": exchange.get("gathered_max_cosine_distance_vs_local_recompute"),
+            "timing": "torch.cuda.Event pair on the launch stream around pad + collective + de-interleave of every timed step "
+                      "(includes the wait for the slowest rank's forward: a collective cannot finish before its last participant arrives)",
+        }
         if extra_f16 is not None:
             out["f16"] = extra_f16
         if extra_split is not None:

@@ -13,9 +13,11 @@ The reference has nothing to mirror here: its entry point hard-codes `device=0`
 from __future__ import annotations
 
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 
 
 def under_torchrun(env=None) -> bool:
@@ -50,16 +52,66 @@ def child_env(env=None) -> dict:
     return out
 
 
-def self_launch(script: str, script_args: list[str], n_ranks: int) -> int:
-    """Run `script script_args` as n_ranks torchrun ranks in a child process; stdout / stderr pass through. Returns the exit code."""
-    cmd = torchrun_command(script, script_args, n_ranks, free_port())
-    proc = subprocess.Popen(cmd, env=child_env())
-    try:
-        return proc.wait()
-    except KeyboardInterrupt:
-        proc.terminate()
+def _stop(proc: subprocess.Popen, grace_s: float = 30.0) -> int:
+    """End the child's whole process group (torchrun + its ranks): SIGTERM, `grace_s` seconds, then SIGKILL."""
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        if proc.poll() is not None:
+            break
         try:
-            return proc.wait(timeout=30)
+            os.killpg(proc.pid, sig)            # start_new_session=True: the child's pid is its process-group id
+        except ProcessLookupError:
+            break
+        try:
+            proc.wait(timeout=grace_s)
         except subprocess.TimeoutExpired:
-            proc.kill()
-            return proc.wait()
+            continue
+    return proc.wait()
+
+
+def _run_once(cmd: list[str], env: dict) -> tuple[int, bool]:
+    """-> (exit code, the rendezvous port was taken).  SIGTERM / SIGHUP / SIGINT to the parent (a driver's timeout, a
+    scheduler, a closed terminal, ^C) end the child's process group before the parent returns 128 + signal: N ranks
+    holding N GPUs are never left behind as orphans.  The child is a CHILD (never exec) in a session of its own."""
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True, stderr=subprocess.PIPE)
+    got = []
+
+    def on_signal(signum, frame):
+        got.append(signum)
+        raise KeyboardInterrupt
+
+    port_taken = [False]
+
+    def relay():                                   # stderr passes through; the only thing read from it is the bind failure
+        for line in iter(proc.stderr.readline, b""):
+            if b"EADDRINUSE" in line or b"ddress already in use" in line:
+                port_taken[0] = True
+            sys.stderr.buffer.write(line)
+            sys.stderr.buffer.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    handled = (signal.SIGTERM, signal.SIGHUP, signal.SIGINT)
+    main_thread = threading.current_thread() is threading.main_thread()
+    old = {s: signal.signal(s, on_signal) for s in handled} if main_thread else {}
+    try:
+        code = proc.wait()
+    except KeyboardInterrupt:
+        _stop(proc)
+        code = 128 + (got[0] if got else signal.SIGINT)
+    finally:
+        for s, h in old.items():
+            signal.signal(s, h)
+    t.join(timeout=5)
+    return code, port_taken[0]
+
+
+def self_launch(script: str, script_args: list[str], n_ranks: int) -> int:
+    """Run `script script_args` as n_ranks torchrun ranks in a child process; stdout / stderr pass through. Returns the exit
+    code.  `free_port` closes its probe socket before torchrun binds the port, so another job can take it in between: a
+    child that dies on the bind is started again on a fresh port (at most three times)."""
+    code = 1
+    for _ in range(3):
+        code, port_taken = _run_once(torchrun_command(script, script_args, n_ranks, free_port()), child_env())
+        if code == 0 or not port_taken or code >= 128:
+            break
+    return code

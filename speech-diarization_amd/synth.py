@@ -152,10 +152,12 @@ def synthetic_segments(seed: int, batch: int, n_samples: int, std: float = 0.1) 
     return np.clip(x, -1.0, 1.0)
 
 
-def synthetic_segments_device(seed: int, batch: int, n_samples: int, device, std: float = 0.1, first_row: int = 0, chunk_rows: int = 500):
+def synthetic_segments_device(seed: int, batch: int, n_samples: int, device, std: float = 0.1, first_row: int = 0, chunk_rows: int = 500,
+                              row_stride: int = 1):
     """`synthetic_segments` generated ON the device (counter-based generator, seed 0,
     N(0, std^2) clipped to [-1, 1]): the same splitmix64 counter stream in int64 torch arithmetic, Box-Muller in
-    float64.  Rows [first_row, first_row + batch) of the stream, so ranks can own disjoint rows of one data set.
+    float64.  Rows first_row + k * row_stride (k < batch) of the stream, so ranks can own disjoint rows of one data set
+    (row_stride = world size, first_row = rank: the round-robin shard of `dist.shard_indices`).
     Equal to the numpy generator up to the device's float64 log / cos rounding (<= 1 f32 ulp)."""
     import torch
     key = ((seed & 0xFFFFFFFF) << 32) ^ (zlib.crc32(f"seg.{n_samples}".encode()) & 0xFFFFFFFF)
@@ -180,7 +182,8 @@ def synthetic_segments_device(seed: int, batch: int, n_samples: int, device, std
     out = torch.empty((batch, n_samples), dtype=torch.float32, device=device)
     for lo in range(0, batch, chunk_rows):
         hi = min(batch, lo + chunk_rows)
-        idx = torch.arange((first_row + lo) * n_samples, (first_row + hi) * n_samples, dtype=torch.int64, device=device)
+        rows = first_row + row_stride * torch.arange(lo, hi, dtype=torch.int64, device=device)
+        idx = (rows[:, None] * n_samples + torch.arange(n_samples, dtype=torch.int64, device=device)[None, :]).reshape(-1)
         z = torch.sqrt(-2.0 * torch.log(unit(idx * 2))) * torch.cos(2.0 * math.pi * unit(idx * 2 + 1))
         out[lo:hi] = (std * z).to(torch.float32).clamp_(-1.0, 1.0).view(hi - lo, n_samples)
     return out

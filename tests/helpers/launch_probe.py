@@ -24,6 +24,12 @@ def main():
     if rank == 0:
         print(json.dumps({"ranks": world, "n_ranks_seen": int(ones.item()), "rows": int(full.shape[0]),
                           "order_ok": bool((full[:, 0] == torch.arange(3 * world) % world).all()), "argv": sys.argv[1:]}), flush=True)
+    if "--hang" in sys.argv:                        # a job the parent has to be told to stop: every rank reports its pid, then sleeps
+        import time
+        d = sys.argv[sys.argv.index("--hang") + 1]
+        with open(os.path.join(d, f"rank{rank}.pid"), "w") as f:
+            f.write(str(os.getpid()))
+        time.sleep(600)
     if "--fail" in sys.argv and rank == world - 1:
         raise SystemExit(7)
     if world > 1:

@@ -46,6 +46,37 @@ def test_parent_relays_a_failing_rank():
     assert res.returncode != 0
 
 
+def test_sigterm_to_the_parent_ends_every_rank(tmp_path):
+    """A driver's timeout or a scheduler signals the PARENT: torchrun and its ranks (which would hold the GPUs) must go with it."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    parent = subprocess.Popen([sys.executable, PROBE, "--gpus", "2", "--hang", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    pid_files = [tmp_path / "rank0.pid", tmp_path / "rank1.pid"]
+    deadline = time.time() + 300
+    while not all(f.exists() and f.read_text() for f in pid_files):
+        assert time.time() < deadline and parent.poll() is None, "ranks never started"
+        time.sleep(0.2)
+    pids = [int(f.read_text()) for f in pid_files]
+    parent.send_signal(signal.SIGTERM)
+    assert parent.wait(timeout=90) == 128 + signal.SIGTERM
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:                                        # a zombie waiting for init to reap it is not a live rank
+            return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0] != "Z"
+        except OSError:
+            return False
+
+    deadline = time.time() + 30
+    while any(alive(p) for p in pids) and time.time() < deadline:
+        time.sleep(0.2)
+    assert not any(alive(p) for p in pids)
+
+
 def test_bench_parent_launches_without_touching_the_gpu():
     """No GPU in this container: the ranks of `bench.py --gpus 2` must each stop at "needs a GPU"; the parent itself never
     asks for one (it would raise before launching) and returns the job's non-zero exit code."""
