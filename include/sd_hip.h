@@ -51,7 +51,7 @@ typedef void* sd_stream_t; /* hipStream_t */
 #define SD_ERR_WORKSPACE (-3)
 #define SD_ERR_HIP (-4)
 
-#define SD_ABI_VERSION 9
+#define SD_ABI_VERSION 10
 
 int sd_abi_version(void);
 /* sizeof of the structs below as this library was compiled (which: 0 sd_conv_args, 1 sd_layer, 2 sd_se_res2_block,
@@ -65,11 +65,12 @@ int sd_device_count(void);
  * roofline figures.  While enabled every launch of the named kernel families is
  * bracketed by two events; sd_profile_read synchronises them and returns the summed
  * duration, the launch count and the summed algorithmic work (flops for
- * SD_PROF_CONV_GEMM / SD_PROF_CONV_WIDE, bytes for SD_PROF_FBANK) since the last sd_profile_enable(1). */
+ * SD_PROF_CONV_GEMM / SD_PROF_CONV_WIDE / SD_PROF_SEG_SPLITK, bytes for SD_PROF_FBANK) since the last sd_profile_enable(1). */
 #define SD_PROF_CONV_GEMM 0
 #define SD_PROF_FBANK 1
 #define SD_PROF_CONV_WIDE 2   /* the 256x256 ring kernels of the wide layers (cout >= 1024), f32 and f16 */
-#define SD_PROF_KINDS 3
+#define SD_PROF_SEG_SPLITK 3  /* per-segment layers that took the grid split-K pair of sd_seg_gemm_f32 (one record per layer) */
+#define SD_PROF_KINDS 4
 int sd_profile_enable(int on);
 int sd_profile_read(int kind, double* ms, long long* launches, double* work);
 
@@ -103,8 +104,9 @@ size_t sd_fbank_workspace_bytes(const sd_fbank_plan* plan, int B, int n);
  * mean_norm != 0 subtracts each utterance's per-bin mean over T.
  * Input domain: samples with |x| <= 16 are processed exactly (audio is normalised to [-1, 1] everywhere on this
  * path); larger magnitudes are clipped to +-16 (the split-f16 DFT scales the folded sums by 2^10 and they must
- * stay inside the f16 range), so any finite input gives finite features.  Precondition: finite samples (a NaN or
- * infinite sample gives unspecified features for ITS row; other rows are unaffected). */
+ * stay inside the f16 range), so any finite input gives finite features; an infinite sample saturates like any
+ * other magnitude above 16.  A NaN sample makes every feature of ITS row NaN (what the reference's utterance-level
+ * floor and mean over T do with it; the row's embedding is then NaN as well); other rows are unaffected. */
 int sd_fbank_f32(const sd_fbank_plan* plan, const float* wav_dev, int B, int n,
                  int mean_norm, float* out_dev, int ld_out,
                  void* ws_dev, size_t ws_bytes, sd_stream_t stream);

@@ -26,8 +26,8 @@ SD_TUNE_HALF_TILES = 5
 SD_TUNE_TILE_ROWS = 6
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
-SD_ABI_VERSION = 9
-SD_PROF_CONV_GEMM, SD_PROF_FBANK, SD_PROF_CONV_WIDE = 0, 1, 2
+SD_ABI_VERSION = 10
+SD_PROF_CONV_GEMM, SD_PROF_FBANK, SD_PROF_CONV_WIDE, SD_PROF_SEG_SPLITK = 0, 1, 2, 3
 
 
 def profile_enable(on: bool) -> None:

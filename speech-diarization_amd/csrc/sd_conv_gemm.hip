@@ -1304,6 +1304,7 @@ extern "C" int sd_seg_gemm_f32(const sd_conv_args* a, void* scratch, size_t scra
       !a->x || !a->w || !a->y || a->cin <= 0 || a->cin > a->cin_pad || a->o_col0 < 0 || a->o_col0 + a->cout > a->ldo || a->a_col0 < 0 || a->a_col0 + a->cin > a->lda)
     return sd_conv1d_cl_f32(a, stream);
   float* part = static_cast<float*>(scratch);
+  SdProfScope prof(SD_PROF_SEG_SPLITK, static_cast<hipStream_t>(stream), 2.0 * (double)a->M * (double)a->cout * (double)a->cin);
   hipLaunchKernelGGL(seg_gemm_partial_f32_kernel, dim3((unsigned)(tiles * nsplit)), dim3(256), 0, static_cast<hipStream_t>(stream), *a, nsplit, groups, part);
   SD_CHECK_LAUNCH("seg_gemm_partial_f32_kernel");
   hipLaunchKernelGGL(seg_gemm_reduce_f32_kernel, dim3((unsigned)(tiles * 4)), dim3(256), 0, static_cast<hipStream_t>(stream), *a, nsplit, part);

@@ -67,7 +67,18 @@ Buffers carve(const sd_ecapa_weights* w, int B, int T, void* ws, int act_dtype) 
   b.stats = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
   b.gbias = static_cast<float*>(c.take((size_t)B * w->att_channels, 4));
   b.pooled = static_cast<float*>(c.take((size_t)B * 2 * Cm, 4));
-  b.skp_bytes = B <= 256 ? (size_t)4 << 20 : 0;
+  // scratch of the grid split-K (M <= 256 rows): the largest of the three per-segment layers that use it (final FC at B = 256: 4.7 MB)
+  b.skp_bytes = 0;
+  if (B <= 256) {
+    size_t need = sd_seg_gemm_scratch_bytes(B, w->fc.cin_pad, w->fc.cout);
+    const size_t g = sd_seg_gemm_scratch_bytes(B, w->asp_tdnn_g.cin_pad, w->asp_tdnn_g.cout);
+    need = g > need ? g : need;
+    for (int i = 0; i < w->n_blocks; ++i) {
+      const size_t s1 = sd_seg_gemm_scratch_bytes(B, w->blocks[i].se1.cin_pad, w->blocks[i].se1.cout);
+      need = s1 > need ? s1 : need;
+    }
+    b.skp_bytes = (need + 255) & ~(size_t)255;
+  }
   b.skp = c.take(b.skp_bytes, 1);
   b.wpk_bytes = act_dtype == SD_DT_F16 ? sd_res2net_chain_workspace_bytes(w->res2_scale - 1) : 0;
   b.wpk = c.take(b.wpk_bytes, 1);
@@ -242,7 +253,9 @@ int forward(const sd_ecapa_weights* w, const float* feats, int B, int T, float* 
   const long nt = sd_f16_narrow_tiles().load(std::memory_order_relaxed);      // one snapshot per forward
   // rows per unit of the column statistics, for sizing them: the exact-f32 operator may pick tiles of 80 / 96 / 112 rows (small launches);
   // the f16 and split kernels always write units of 128
-  const size_t stat_unit = (dt == SD_DT_F32 && !wsplit) ? 80 : 128;
+  // the statistics buffers are sized for the smallest row unit a launch of this forward can write: an f32 forward can reach the exact
+  // operator's 80 / 96 / 112-row tiles (sd_conv1d_cl_f32_rows) also WITH split weights, whenever run_wide falls through to run_conv
+  const size_t stat_unit = dt == SD_DT_F32 ? 80 : 128;
 
   static const bool colstat_ok = [] {     // SD_COLSTAT=0: A/B switch for measurements
     const char* e = sd_experiment_env("SD_COLSTAT");

@@ -70,6 +70,7 @@ __device__ __forceinline__ float key_f32(int k) {
 #ifndef SD_FB_SCALE
 #define SD_FB_SCALE 1024.f
 #endif
+#define SD_FB_POISON_KEY 0x7FFFFFFF                  // key of an utterance that holds a NaN sample (key_f32 of it is a NaN)
 #define SD_FB_XMAX 16.0f                            // 2 * 16 * 1024 = 32768 < 65504 (f16 max)
 constexpr int V2_XS_W = 5952;                       // per-wave sample image, floats (two spans + skew + alignment slack)
 constexpr int V2_STAGE_BYTES = 16 * 1024;           // basis fragments of one (pass, k step): 4 tiles x 4 kinds x 1 KB
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(256 * V2_GROUPS, 1) void fbank_logmel_kernel(const 
     constexpr int SB = 32;
     auto stage_span = [&](int b, int s0, int len, int off) {
       const long long start = p.starts ? p.starts[b] : (long long)b * p.n;      // first sample of row b in `wav`
+      bool bad = false;                                                         // a NaN sample: the clamp below would launder it into -16
       for (int rel0 = lane + grp * 64 * SB; rel0 < len; rel0 += V2_GROUPS * 64 * SB) {     // (the pair stages alternate batches)
         float v[SB];
         bool okv[SB];
@@ -299,13 +301,19 @@ __global__ __launch_bounds__(256 * V2_GROUPS, 1) void fbank_logmel_kernel(const 
         // zero padding, and saturation at +-SD_FB_XMAX: the folded sums x[k] +- x[400-k], scaled by 2^10, must stay inside
         // the f16 range (|x| <= 16 is exact; beyond it the sample is clipped instead of turning the segment into NaNs)
 #pragma unroll
-        for (int u = 0; u < SB; ++u) v[u] = okv[u] ? __builtin_amdgcn_fmed3f(v[u], -SD_FB_XMAX, SD_FB_XMAX) : 0.f;
+        for (int u = 0; u < SB; ++u) {
+          bad |= okv[u] && v[u] != v[u] && rel0 + 64 * u < len;
+          v[u] = okv[u] ? __builtin_amdgcn_fmed3f(v[u], -SD_FB_XMAX, SD_FB_XMAX) : 0.f;
+        }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
           const int rel = rel0 + 64 * u;
           if (rel < len) xs[off + rel + 4 * (rel / HOP)] = v[u];
         }
       }
+      // the reference's arithmetic would carry the NaN into the utterance's floor and mean, i.e. into every value of its features:
+      // the utterance is marked (the largest key) and the finalize pass writes NaN rows for it
+      if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicMax(p.maxbuf + b, SD_FB_POISON_KEY);
     };
     if (nfA > 0) stage_span(bA, tA * HOP - NFFT / 2, lenA, 0);
     if (nfB > 0) stage_span(bA + 1, -NFFT / 2, (nfB - 1) * HOP + NFFT, offB);
@@ -415,7 +423,14 @@ __global__ void fbank_finalize_kernel(float* out, int ld_out, int T, int n_mels,
   const int r = tid / n_mels;
   const bool active = r < R;
   float* base = out + (size_t)b * T * ld_out;
-  const float thr = use_floor ? key_f32(maxbuf[b]) - top_db : -INFINITY;
+  const int key = maxbuf[b];
+  if (key == SD_FB_POISON_KEY) {                      // a NaN sample somewhere in the utterance: NaN features, as the reference's floor / mean would give
+    if (active)
+      for (int t = r; t < T; t += R) base[(size_t)t * ld_out + c] = __int_as_float(0x7FC00000);
+    return;
+  }
+  if (!use_floor && !mean_norm) return;               // (raw features: the pass only exists to mark NaN utterances)
+  const float thr = use_floor ? key_f32(key) - top_db : -INFINITY;
   float s = 0.f;
   if (active && mean_norm)
     for (int t = r; t < T; t += R) s += fmaxf(base[(size_t)t * ld_out + c], thr);
@@ -610,7 +625,7 @@ static int fbank_launch(const sd_fbank_plan* plan, const float* wav_dev, long lo
   }
   SD_CHECK_LAUNCH("fbank_logmel_kernel");
   const int use_floor = plan->log_mode == SD_LOG_DB_TOPDB && plan->top_db >= 0.f;
-  if (use_floor || mean_norm) {
+  {
     int R = 320 / plan->n_mels; if (R < 1) R = 1; if (R > T) R = T;
     int threads = ((R * plan->n_mels + 63) / 64) * 64;
     hipLaunchKernelGGL(fbank_finalize_kernel, dim3((unsigned)B), dim3(threads), (size_t)R * plan->n_mels * sizeof(float),

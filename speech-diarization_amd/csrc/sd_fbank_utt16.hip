@@ -57,7 +57,7 @@ constexpr int U16_THREADS = 512;
 constexpr int U16_MAX_GROUPS = (((U16_MAX_T * HOP - 1) + NFFT + 3) / 4 + U16_THREADS - 1) / U16_THREADS;
 constexpr int A2_BYTES = 16 * 1024;
 constexpr int RING_BYTES = 16 * 1024;   // two chunks of eight 1 KB fragments: the streamed tables, shared by the eight waves
-constexpr int SCRATCH_FLOATS = 64;      // [0..15] wave maxima of the log-mel rows, [16..23] of |x|
+constexpr int SCRATCH_FLOATS = 64;      // [0..15] wave maxima of the log-mel rows, [16..23] of |x|, [24..31] "this wave saw a NaN sample"
 constexpr int LDS_LIMIT = 160 * 1024;
 constexpr float XMAX = 16.f;
 constexpr double A1SCALE = 32.0, A2SCALE = 32.0;
@@ -251,6 +251,7 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
     };
     f32x4 v[U16_MAX_GROUPS];
     float amax = 0.f;
+    bool bad = false;           // a NaN sample (v_med3 alone would launder it into -XMAX): the utterance's features become NaN, see the store phase
 #pragma unroll
     for (int u = 0; u < U16_MAX_GROUPS; ++u) {
       const int g = tid + U16_THREADS * u;
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
       ok = ok && gi >= 0 && gi < p.n_total;
       gi = gi < 0 ? 0 : (gi >= p.n_total ? p.n_total - 1 : gi);
       float x = p.wav[gi];
+      bad |= ok && x != x;
       x = ok ? __builtin_amdgcn_fmed3f(x, -XMAX, XMAX) : 0.f;
       amax = fmaxf(amax, fabsf(x));
       img[i + i / HOP] = __float_as_uint(x);
@@ -290,11 +292,13 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
     for (int u = 0; u < U16_MAX_GROUPS; ++u)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        bad |= v[u][c] != v[u][c];
         v[u][c] = __builtin_amdgcn_fmed3f(v[u][c], -XMAX, XMAX);
         amax = fmaxf(amax, fabsf(v[u][c]));
       }
     amax = sd_wave_max(amax);
-    if (lane == 0) scratch[16 + wid] = amax;
+    const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if (lane == 0) { scratch[16 + wid] = amax; scratch[24 + wid] = wave_bad ? 1.f : 0.f; }
     U16_STAMP(1);
     __syncthreads();
     float mx = scratch[16];
@@ -592,6 +596,22 @@ __global__ __launch_bounds__(U16_THREADS, 2) void fbank_utt16_kernel(const U16Ar
     __syncthreads();
   }
   float* const orow = p.out + (size_t)b * p.T * p.ld_out;
+  {
+    // a NaN sample anywhere in the utterance: the reference's arithmetic carries it into the utterance maximum (top_db floor) and the mean over
+    // T, i.e. into every value of the utterance's features.  Here the sample was clamped on its way into the f16 image, so the rows are
+    // overwritten: bad input shows as NaN features (and a NaN embedding), never as a plausible finite row.
+    float nb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) nb += scratch[24 + i];
+    if (nb != 0.f) {
+      const int total = p.T * p.n_mels;
+      for (int e = tid; e < total; e += U16_THREADS) {
+        const int t = e / p.n_mels, c = e - t * p.n_mels;
+        orow[(size_t)t * p.ld_out + c] = __int_as_float(0x7FC00000);
+      }
+      return;
+    }
+  }
   if ((p.n_mels & 3) == 0 && (p.ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15u) == 0) {
     const int per_row = p.n_mels >> 2;
     const int total = p.T * per_row;

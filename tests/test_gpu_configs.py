@@ -78,9 +78,17 @@ def test_reference_batch_sizes_agree_with_a_small_batch_and_the_oracle(dev, prec
     pick = [0, 1, 7, 15, 150, 299]
     small = eng.embed(wav[pick])
     tol = 1e-9 if precision == "f32" else 2e-4
-    for B in (16, 24, 32, 48, 64, 100, 128, 256, 257, 300):
+    from speech_diarization_amd import _native
+    for B in (16, 24, 32, 48, 64, 100, 128, 224, 256, 257, 300):
         emb = eng.embed(wav[:B])
-        assert torch.equal(emb, eng.embed(wav[:B])), B
+        _native.profile_enable(True)
+        again = eng.embed(wav[:B])
+        _, splitk_layers, _ = _native.profile_read(_native.SD_PROF_SEG_SPLITK)
+        _native.profile_enable(False)
+        assert torch.equal(emb, again), B
+        # the five per-segment layers with K >= 512 (3 x SE squeeze FC, global-context bias, final FC) take the grid split-K pair up to
+        # 256 rows: the forward's scratch is sized for the largest of them (4 MB were 0.7 MB short for the final FC at 225..256)
+        assert splitk_layers == (5 if B <= 256 else 0), (B, splitk_layers)
         rows = [i for i, r in enumerate(pick) if r < B]
         cos = 1.0 - torch.nn.functional.cosine_similarity(emb[[pick[i] for i in rows]].double(), small[rows].double(), dim=1)
         assert float(cos.max()) < tol, (B, float(cos.max()))

@@ -275,10 +275,30 @@ def test_fbank_out_of_range_samples_are_clipped_not_nan(dev, kind):
     assert np.abs(got[0] - ref_fn(big[:1])[0]).max() < tol
     clipped = np.clip(big, -16.0, 16.0)
     assert np.abs(got - ref_fn(clipped)).max() < tol
-    nan = wav.copy(); nan[1, 777] = np.nan; nan[1, 9000] = np.inf         # precondition violated for row 1: its features are
-    g2 = fbank_device(torch.from_numpy(nan).to(dev), plan, mean_norm=False).cpu().numpy()   # unspecified, its neighbours untouched
-    g1 = fbank_device(torch.from_numpy(wav).to(dev), plan, mean_norm=False).cpu().numpy()
-    assert np.array_equal(g2[0], g1[0]) and np.array_equal(g2[2], g1[2])
+    nan = wav.copy(); nan[1, 777] = np.nan; nan[2, 9000] = np.inf         # a NaN sample: NaN features for ITS row (sd_hip.h), an infinite
+    g1 = fbank_device(torch.from_numpy(wav).to(dev), plan, mean_norm=False).cpu().numpy()   # one saturates; the neighbours are untouched
+    for mean_norm in (False, True):
+        g2 = fbank_device(torch.from_numpy(nan).to(dev), plan, mean_norm=mean_norm).cpu().numpy()
+        assert np.isnan(g2[1]).all() and np.isfinite(g2[0]).all() and np.isfinite(g2[2]).all()
+        if not mean_norm:
+            assert np.array_equal(g2[0], g1[0])
+
+
+@pytest.mark.parametrize("n", [16000, 48000])
+def test_a_nan_sample_gives_a_nan_embedding_for_its_row_only(dev, n):
+    """the clamp in front of the f16 sample image must not launder a NaN into a plausible embedding.  Both fbank kernels
+    (one launch up to 201 frames, the folded one beyond), first / middle / last sample, windows read in place included."""
+    from speech_diarization_amd import synth
+    from speech_diarization_amd.engine import EmbeddingEngine
+    sd = synth.make_ecapa_state_dict(1234, synth.EcapaConfig.small(128))
+    eng = EmbeddingEngine(sd, dev)
+    wav = synth.synthetic_segments(3, 5, n, std=0.2)
+    clean = eng.embed(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    bad = wav.copy()
+    bad[0, 0] = np.nan; bad[2, n // 2] = np.nan; bad[4, n - 1] = np.nan
+    got = eng.embed(torch.from_numpy(bad).to(dev)).cpu().numpy()
+    assert np.isnan(got[[0, 2, 4]]).all()
+    assert np.array_equal(got[[1, 3]], clean[[1, 3]])
 
 
 def test_fbank_achieved_error_is_recorded(dev, capsys):
