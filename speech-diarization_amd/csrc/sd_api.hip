@@ -112,11 +112,11 @@ extern "C" int sd_profile_read(int kind, double* ms, long long* launches, double
   return SD_OK;
 }
 
-static int pad32(int d) { return (d + 31) & ~31; }
+static int pad32(int d) { return (int)(((long)d + 31) & ~31L); }     // (callers bound d: a row of more than 2^31 - 32 floats is refused)
 
 extern "C" size_t sd_cosine_workspace_bytes(int N, int D) {
   if (N <= 0 || D <= 0) return 0;
-  return ((size_t)N * pad32(D) * sizeof(float) + 255) & ~(size_t)255;
+  return ((size_t)N * (((size_t)D + 31) & ~(size_t)31) * sizeof(float) + 255) & ~(size_t)255;
 }
 
 // sklearn.metrics.pairwise.cosine_similarity(X): K = normalize(X) @ normalize(X).T with
@@ -135,7 +135,7 @@ extern "C" int sd_cosine_affinity_f32(const float* x, int N, int D, float* out, 
 // never moved over xGMI, only the N x D embeddings are).
 extern "C" int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row_lo, int row_hi, float* out, int ldo,
                                            void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
-  SD_CHECK_ARG(N >= 0 && D > 0, "sd_cosine_affinity_f32: N=%d D=%d", N, D);
+  SD_CHECK_ARG(N >= 0 && D > 0 && D <= (1 << 24), "sd_cosine_affinity_f32: N=%d D=%d", N, D);
   SD_CHECK_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= N, "sd_cosine_affinity_rows_f32: bad row block [%d,%d) of %d", row_lo, row_hi, N);
   if (N == 0 || row_lo == row_hi) return SD_OK;
   SD_CHECK_ARG(x && out && ws_dev, "sd_cosine_affinity_f32: null pointer");
@@ -170,7 +170,7 @@ extern "C" int sd_cosine_affinity_rows_f32(const float* x, int N, int D, int row
 // the SAME packed matrix on both sides; the epilogue takes the 2^-8 back.  The whole matrix is computed on and above the diagonal only
 // (sd_affinity.hip: 128 x 128 tiles, two workgroups per CU) and every off-diagonal tile is stored twice from the same accumulators, both
 // copies as 256-byte runs; what is left is writing 4 N^2 bytes.
-static int pad32s(int d) { return (d + 31) & ~31; }
+static int pad32s(int d) { return pad32(d); }
 
 extern "C" size_t sd_cosine_split16_workspace_bytes(int N, int D) {
   if (N <= 0 || D <= 0) return 0;
@@ -189,7 +189,7 @@ __global__ void fill_f32_kernel(float* p, int n, float v) {
 
 extern "C" int sd_cosine_affinity_rows_split16(const float* x, int N, int D, int row_lo, int row_hi, float* out, int ldo,
                                                void* ws_dev, size_t ws_bytes, sd_stream_t stream) {
-  SD_CHECK_ARG(N >= 0 && D > 0, "sd_cosine_affinity_rows_split16: N=%d D=%d", N, D);
+  SD_CHECK_ARG(N >= 0 && D > 0 && D <= (1 << 24), "sd_cosine_affinity_rows_split16: N=%d D=%d", N, D);
   SD_CHECK_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= N, "sd_cosine_affinity_rows_split16: bad row block [%d,%d) of %d", row_lo, row_hi, N);
   if (N == 0 || row_lo == row_hi) return SD_OK;
   SD_CHECK_ARG(x && out && ws_dev, "sd_cosine_affinity_rows_split16: null pointer");

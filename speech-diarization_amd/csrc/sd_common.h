@@ -77,6 +77,18 @@ __device__ __forceinline__ float sd_split16_clamp(float v) {
   return v != v ? v : c;
 }
 
+// max(x, lo) that KEEPS a NaN x (ReLU: lo = 0; identity: lo = -inf).  v_max_f32 returns the other operand for a NaN, so a NaN activation
+// (say the features sd_fbank writes for an utterance with a NaN sample) would become 0 in the first ReLU and the segment would leave the
+// network with a plausible finite embedding; torch's relu / clamp propagate it [REF speech_encode.py:77 via speechbrain's TDNNBlock].
+// One v_cmp + v_cndmask instead of one v_max per output element (-DSD_RELU_VMAX: the old form, for A/B timing only).
+__device__ __forceinline__ float sd_max_keep_nan(float x, float lo) {
+#ifdef SD_RELU_VMAX
+  return fmaxf(x, lo);
+#else
+  return x < lo ? lo : x;
+#endif
+}
+
 __device__ __forceinline__ float sd_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -1280,8 +1280,8 @@ static int conv1d_cl_f32_impl(const sd_conv_args* a, sd_stream_t stream, bool sy
 static int seg_gemm_shape(int M, int cin_pad, int cout, int* groups, int* nsplit, long* tiles) {
   if (M <= 0 || M > 256 || cin_pad < 512 || cin_pad % 32 != 0 || cout <= 0) return 0;
   *groups = cin_pad >= 2048 ? 8 : 4;
-  *nsplit = (cin_pad + 32 * *groups - 1) / (32 * *groups);
-  *tiles = (long)((M + SK_T - 1) / SK_T) * ((cout + SK_T - 1) / SK_T);
+  *nsplit = (int)(((long)cin_pad + 32 * *groups - 1) / (32 * *groups));
+  *tiles = (long)((M + SK_T - 1) / SK_T) * (((long)cout + SK_T - 1) / SK_T);
   return *nsplit >= 2;
 }
 

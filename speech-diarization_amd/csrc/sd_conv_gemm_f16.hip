@@ -463,7 +463,7 @@ __device__ __forceinline__ void sd_direct_epilogue(const sd_conv_args& p, ACC (&
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[t][r] = fmaxf(acc[mi][2 * jp + t][r] + b[t][r], lo) * s[t][r] + h[t][r];
+        for (int r = 0; r < 4; ++r) v[t][r] = sd_max_keep_nan(acc[mi][2 * jp + t][r] + b[t][r], lo) * s[t][r] + h[t][r];
       if (cs) {
         const int part = 16 * mi + fr >= rb ? 1 : 0;
 #pragma unroll

@@ -24,8 +24,8 @@ namespace {
 
 struct Carver {
   char* base; size_t off;
-  void* take(size_t elems, size_t esz) {
-    void* p = base + off;
+  void* take(size_t elems, size_t esz) {          // base == nullptr: a sizing pass (no pointer is formed from a null base)
+    void* p = base ? base + off : nullptr;
     off += (elems * esz + 255) & ~(size_t)255;
     return p;
   }

@@ -23,7 +23,7 @@
 
 __device__ __forceinline__ float sd_apply_act(float v, int act) {
   switch (act) {
-    case SD_ACT_RELU: return fmaxf(v, 0.0f);
+    case SD_ACT_RELU: return sd_max_keep_nan(v, 0.0f);
     case SD_ACT_TANH: return tanhf(v);
     case SD_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     default: return v;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void sd_store_rows(const sd_conv_args& p, const float
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = fmaxf(v[i][e] + b8[e], lo) * s8[e] + h8[e];
+      for (int e = 0; e < 8; ++e) v[i][e] = sd_max_keep_nan(v[i][e] + b8[e], lo) * s8[e] + h8[e];
       const bool live = FULL || c0 + i < np;
       if (YSPLIT && sizeof(TO) == 4 && p.y_dtype == SD_DT_SPLIT16) {      // (YSPLIT: only the kernels whose host entry accepts such a y)
         // y as SD_DT_SPLIT16 rows of p.ldo VALUE columns (what sd_split16_pack_f32 would make of the f32 result, bit for bit:
@@ -280,7 +280,7 @@ __device__ __forceinline__ void sd_store_tile(const sd_conv_args& p, float* Cs, 
         const int part = (row >= rb ? 1 : 0) + (row >= rb + p.T ? 1 : 0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float x = fmaxf(v[e] + b8[e], lo) * s8[e];     // = y - shift
+          const float x = sd_max_keep_nan(v[e] + b8[e], lo) * s8[e];     // = y - shift
 #pragma unroll
           for (int q = 0; q < SP; ++q) {
             st[q][e] += part == q ? x : 0.f;

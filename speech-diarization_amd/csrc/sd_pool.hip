@@ -480,7 +480,7 @@ extern "C" int sd_se_scale_residual_f32(const float* x, int ldx, const float* ga
 
 extern "C" size_t sd_colstat_floats(int M, int cout) {
   if (M <= 0 || cout <= 0) return 0;
-  return (size_t)((M + 127) / 128) * 6 * (size_t)cout;
+  return (((size_t)M + 127) / 128) * 6 * (size_t)cout;
 }
 
 extern "C" int sd_colstat_finish_dt(const float* colstat, const float* pivot, const void* y, int y_dtype, int ldy, int y_col0,

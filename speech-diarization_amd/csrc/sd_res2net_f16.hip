@@ -308,7 +308,7 @@ __global__ __launch_bounds__(RC_THREADS) void res2net_chain_f16_kernel(const Cha
         h4 y, u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = fmaxf(acc[tt][4 * g + r] + pb[g][r], 0.f) * ps[g][r] + ph[g][r];
+          const float v = sd_max_keep_nan(acc[tt][4 * g + r] + pb[g][r], 0.f) * ps[g][r] + ph[g][r];
           y[r] = (_Float16)v;
           u[r] = (_Float16)(v + (more ? (float)cn[tt & 1][g][r] : 0.f));
         }
