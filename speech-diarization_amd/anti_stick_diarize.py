@@ -196,7 +196,6 @@ def embed_segments(y: np.ndarray, sr: int, segs: list[Segment], batch_size: int 
     widened by `pad_duration_ms` on both sides first."""
     if len(segs) == 0:
         return np.empty((0, EMB_DIM), dtype=np.float32)
-    encode = encode or _default_encode()
     min_len = int(min_duration_ms / 1000.0 * sr)
     widen = int(pad_duration_ms / 1000.0 * sr)
 
@@ -207,13 +206,20 @@ def embed_segments(y: np.ndarray, sr: int, segs: list[Segment], batch_size: int 
             piece = y[max(0, s - widen): min(len(y), e + widen)]
         return piece
 
-    chunks = []
+    batches = []
     for lo in range(0, len(segs), batch_size):
         pieces = [snippet(seg) for seg in segs[lo: lo + batch_size]]
         batch = np.zeros((len(pieces), max(len(p) for p in pieces)), dtype=np.float32)
         for row, piece in zip(batch, pieces):
             row[: len(piece)] = piece
-        chunks.append(encode(batch))
+        batches.append(batch)
+    if encode is None:
+        # the batches are independent and each keeps its own padded length [REF :163-166]: two of them in flight on the card
+        # (copies under compute, one launch's tail under the other's kernels), every batch bit for bit what `ecapa_encode_batch` returns
+        from .speech_encode import ecapa_encode_batches
+        chunks = ecapa_encode_batches(batches)
+    else:
+        chunks = [encode(b) for b in batches]
     return np.concatenate(chunks, axis=0)
 
 

@@ -220,6 +220,16 @@ class EmbeddingEngine:
                 self._ws[i] = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def sibling(self) -> "EmbeddingEngine":
+        """A second engine over the SAME packed weights and fbank tables (read-only on the device) with a workspace and a lock of
+        its own: two siblings can run forwards on two streams at once (`HipEcapaEncoder.encode_batches`)."""
+        other = object.__new__(EmbeddingEngine)
+        other.__dict__.update(self.__dict__)
+        other._lock = threading.Lock()
+        other._ws = None
+        other._ws_frozen = False
+        return other
+
     def freeze_workspace(self) -> None:
         """After a hipGraph capture of `embed`: the captured launches hold the workspace pointers, so it may no longer move."""
         self._ws_frozen = True

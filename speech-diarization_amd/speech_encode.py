@@ -17,6 +17,7 @@ There is no CPU fallback.
 from __future__ import annotations
 
 import os
+import threading
 import warnings
 from functools import lru_cache
 from pathlib import Path
@@ -129,6 +130,8 @@ class HipEcapaEncoder:
         self.precision = precision
         self.engine = EmbeddingEngine(state_dict, self.device, max_batch=max_batch, precision=precision)
         self.embedding_dim = self.engine.dim
+        self._lanes = []
+        self._lanes_lock = threading.Lock()
 
     @torch.inference_mode()
     def encode_batch(self, wavs: torch.Tensor, wav_lens: torch.Tensor | None = None, normalize: bool = False) -> torch.Tensor:
@@ -143,6 +146,77 @@ class HipEcapaEncoder:
         return self.engine.embed(x).unsqueeze(1)
 
     __call__ = encode_batch
+
+    # -- several independent batches in flight
+    class _Lane:
+        """One of the pipeline's slots: a stream, an engine (own workspace over the shared weights), pinned staging buffers."""
+
+        def __init__(self, engine: EmbeddingEngine, device: torch.device):
+            self.engine = engine
+            self.stream = torch.cuda.Stream(device)
+            self.done = torch.cuda.Event()
+            self.host_in = None          # pinned f32, grows
+            self.host_out = None         # pinned f32 [rows, dim], grows
+            self.pending = None          # (index of the batch in flight, rows)
+
+        def staging(self, rows: int, n: int, dim: int):
+            if self.host_in is None or self.host_in.numel() < rows * n:
+                self.host_in = torch.empty((rows * n,), dtype=torch.float32).pin_memory()
+            if self.host_out is None or self.host_out.shape[0] < rows:
+                self.host_out = torch.empty((rows, dim), dtype=torch.float32).pin_memory()
+            return self.host_in[: rows * n].view(rows, n), self.host_out[:rows]
+
+    @torch.inference_mode()
+    def encode_batches(self, batches, lanes: int = 2) -> list:
+        """`[ecapa_encode_batch(b) for b in batches]` with up to `lanes` batches in flight: the reference's callers embed a recording
+        as a sequence of independent batches (32 segments zero-padded to the batch's longest [REF anti_stick_diarize.py:150-171], 128
+        reassignment windows [REF :398-430]) and synchronise after every one, so the card idles while a batch crosses PCIe, and every
+        kernel boundary of a small launch (the previous kernel's last workgroups draining, the next one's first ramping up) is
+        exposed.  Here batch i + 1 is staged (pinned memory), copied and launched on a second stream while batch i computes: copies
+        overlap compute and one launch's tail is filled by the other stream's kernels.  Every batch runs the same kernels on the
+        same shapes as the one-at-a-time call, in a workspace of its own: results are BITWISE those of `ecapa_encode_batch(b)`.
+        batches: iterable of float arrays [B_i, n_i] (any mix of shapes) -> list of fresh numpy arrays [B_i, 192]."""
+        batches = [np.ascontiguousarray(b, dtype=np.float32) for b in batches]
+        for b in batches:
+            assert b.ndim == 2
+        out: list = [None] * len(batches)
+        if not batches:
+            return out
+        with self._lanes_lock:
+            return self._encode_batches_locked(batches, out, max(1, min(int(lanes), len(batches))))
+
+    def _encode_batches_locked(self, batches, out, n_lanes):
+        # every lane runs on a SIBLING of self.engine (own workspace): a concurrent `encode_batch` on the main engine from another
+        # thread (the reference's web UI calls the pipeline from a worker thread) never shares a workspace with a lane in flight
+        while len(self._lanes) < n_lanes:
+            self._lanes.append(self._Lane(self.engine.sibling(), self.device))
+        use = self._lanes[:n_lanes]
+
+        def harvest(lane):
+            if lane.pending is not None:
+                i, rows = lane.pending
+                lane.done.synchronize()
+                out[i] = lane.host_out[:rows].numpy().copy()
+                lane.pending = None
+
+        for i, b in enumerate(batches):
+            lane = use[i % len(use)]
+            harvest(lane)                                   # its previous batch: frees the lane's staging buffers
+            rows, n = b.shape
+            if rows == 0:
+                out[i] = np.empty((0, self.embedding_dim), dtype=np.float32)
+                continue
+            h_in, h_out = lane.staging(rows, n, self.embedding_dim)
+            h_in.numpy()[...] = b
+            with torch.cuda.stream(lane.stream):
+                x = h_in.to(self.device, non_blocking=True)
+                emb = lane.engine.embed(x)
+                h_out.copy_(emb, non_blocking=True)
+                lane.done.record(lane.stream)
+            lane.pending = (i, rows)
+        for lane in use:
+            harvest(lane)
+        return out
 
     @torch.inference_mode()
     def encode_windows(self, signal, starts, n: int, rows_per_call: int = 8192, to_host: bool = True):
@@ -172,6 +246,12 @@ def ecapa_encode_batch(wavs: np.ndarray) -> np.ndarray:
         x = torch.from_numpy(np.ascontiguousarray(wavs)).float()
         y = encoder.encode_batch(x).squeeze(1).cpu().numpy()
     return y  # [B, 192]
+
+
+def ecapa_encode_batches(batches, lanes: int = 2) -> list:
+    """`[ecapa_encode_batch(b) for b in batches]`, bit for bit, with `lanes` batches in flight on the card
+    (`HipEcapaEncoder.encode_batches`): what the batch loops of `embed_segments` / `frame_reassign` call."""
+    return using_ecapa_encoder().encode_batches(batches, lanes=lanes)
 
 
 @lru_cache(maxsize=1)

@@ -170,3 +170,30 @@ def test_diarize_on_gpu_equals_diarize_with_the_cpu_encoder(small_encoder):
             g = asd.diarize(conv.wav, 16000, **kw)
             c = asd.diarize(conv.wav, 16000, encode=cpu, **kw)
             assert g and [(s.start, s.end, s.spk) for s in g] == [(s.start, s.end, s.spk) for s in c], (seed, kw)
+
+
+def test_batches_in_flight_give_the_bits_of_one_call_at_a_time(small_encoder):
+    """`ecapa_encode_batches` / `HipEcapaEncoder.encode_batches`: the batch loop of `embed_segments` [REF anti_stick_diarize.py:150-171] with
+    two or three batches in flight on separate streams and workspaces.  Ragged batch sizes and padded lengths (also past the one-launch
+    fbank kernel's 201 frames), an empty batch, more lanes than batches; every batch bit for bit what `ecapa_encode_batch` returns, fresh
+    arrays, inputs untouched, and `embed_segments` on the GPU equal to its loop with the one-at-a-time encoder."""
+    from speech_diarization_amd import anti_stick_diarize as asd, speech_encode, synth
+    enc, _ = small_encoder
+    shapes = [(32, 16000), (7, 40000), (32, 20800), (1, 8000), (0, 16000), (32, 16000), (13, 33600), (32, 12000), (5, 16160)]
+    batches = [synth.synthetic_segments(40 + i, b, n) for i, (b, n) in enumerate(shapes)]
+    keep = [b.copy() for b in batches]
+    want = [speech_encode.ecapa_encode_batch(b) if len(b) else np.empty((0, 192), np.float32) for b in batches]
+    for lanes in (1, 2, 3, 16):
+        got = speech_encode.ecapa_encode_batches(batches, lanes=lanes)
+        assert len(got) == len(want)
+        for g, w, (b, n) in zip(got, want, shapes):
+            assert isinstance(g, np.ndarray) and g.dtype == np.float32 and g.shape == (b, 192) and g.flags.owndata
+            assert np.array_equal(g, w), (lanes, b, n)
+    assert all(np.array_equal(a, b) for a, b in zip(batches, keep))
+    assert speech_encode.ecapa_encode_batches([]) == []
+    assert np.array_equal(enc.encode_batches(batches[:1], lanes=2)[0], want[0])             # fewer batches than lanes
+    conv = synth.synthetic_conversation(40.0, 2, seed=5)
+    y = conv.wav.astype(np.float32)
+    segs = [asd.Segment(0.3 * k, 0.3 * k + 0.2 + 0.05 * (k % 17)) for k in range(100)]      # 100 segments -> 4 batches of ragged lengths
+    one_at_a_time = asd.embed_segments(y, conv.sr, segs, encode=speech_encode.ecapa_encode_batch)
+    assert np.array_equal(asd.embed_segments(y, conv.sr, segs), one_at_a_time)

@@ -367,10 +367,10 @@ def test_ecapa_split16_small_geometries_match_oracle(dev, width, att, B, n):
 def test_split_sites_keep_nan(dev):
     """every f32 -> (hi, lo) split site clamps to the f16 range AND keeps NaN (`sd_split16_clamp`): the pack kernel, the
     narrow kernel's staging, its SD_DT_SPLIT16 output and the wide kernel's.  A NaN activation reaches the matrix cores as a NaN (it used
-    to become -65504, a finite value) and leaves the other rows' bits alone; +-inf and out-of-range values clamp to +-65504.  What the f16
-    MFMA makes of a NaN operand on gfx950 is -inf, not NaN (tools/probe_nan.py: the plain f16 conv kernel does the same, the exact-f32
-    kernel returns NaN): the affected rows come out non-finite, which is what a caller can test for.  (No activation here: the epilogue's
-    ReLU is `fmaxf(v, 0)`, which maps NaN and -inf to 0 in every precision mode.)"""
+    to become -65504, a finite value) and leaves the other rows' bits alone; +-inf and out-of-range values clamp to +-65504.  The affected
+    rows come out NaN, in the f32 result and in its split twin.  (Round 5: the epilogue's lower clamp keeps a NaN too,
+    `sd_max_keep_nan`; until then `fmaxf(acc, -inf)` turned the matrix cores' NaN into -inf here and a ReLU turned it into 0 -- the
+    "-inf from the f16 MFMA" this test used to describe was that clamp, not the instruction.)"""
     from speech_diarization_amd import ops
     g = torch.Generator().manual_seed(5)
     B, T, cin, cout = 2, 150, 128, 128
@@ -389,7 +389,7 @@ def test_split_sites_keep_nan(dev):
     ysp = torch.zeros((B * T, 2 * cout), device=dev, dtype=torch.float16)
     ops.conv1d_cl_split16(xn, ws, s, T, cin=cin, dil=2, act=None, narrow=True, out=torch.zeros_like(y), out_split=ysp)
     assert torch.equal(ysp.view(torch.int16), ops.split16_pack(y, 0, cout).view(torch.int16))       # NaN rows included, bit for bit
-    assert bool((ysp[hit].float().abs() == 65504.0).any(dim=1).all())                               # (-inf clamps on its way into the split)
+    assert bool(torch.isnan(y[hit]).any(dim=1).all()) and bool(torch.isnan(ysp[hit].float()).any(dim=1).all())     # NaN, not a clamped -inf
     # the pack pass: NaN stays NaN, +-inf / out-of-range clamp
     v = torch.tensor([[float("nan"), float("inf"), -float("inf"), 1e6, -1e6, 1.5, 0.0, -2.25] * 4], device=dev)
     p = ops.split16_pack(v).float()
