@@ -148,6 +148,16 @@ def reference_batches(state_dict, dev, precision):
         med = float(np.median(lat))
         out[f"numpy_batch{batch}_segments_per_s"] = batch / med
         out[f"numpy_batch{batch}_ms_per_call"] = med * 1e3
+        # the same batches as the reference's callers issue them -- a LOOP over independent batches [REF anti_stick_diarize.py:150-171] -- through
+        # `ecapa_encode_batches` (what `embed_segments` calls): two batches in flight on two streams, results bitwise those of the calls above
+        many = [synth.synthetic_segments(50 + i, batch, 32000) for i in range(24 if batch == 32 else 12)]
+        speech_encode.ecapa_encode_batches(many)
+        t0 = time.perf_counter()
+        got = speech_encode.ecapa_encode_batches(many)
+        dt = time.perf_counter() - t0
+        out[f"loop_batch{batch}_two_in_flight_segments_per_s"] = batch * len(many) / dt
+        out[f"loop_batch{batch}_two_in_flight_ms_per_batch"] = dt / len(many) * 1e3
+        out[f"loop_batch{batch}_bitwise_equal_to_single_calls"] = bool(all(np.array_equal(g, speech_encode.ecapa_encode_batch(w)) for g, w in zip(got[:3], many[:3])))
     eng = EmbeddingEngine(state_dict, dev, max_batch=16, precision=precision)
     st = StreamingEmbedder(eng, channels=16, window_s=2.0, hop_s=0.25, use_graph=True)
     chunk = torch.randn(16, 4000, device=dev) * 0.1
@@ -162,7 +172,8 @@ def reference_batches(state_dict, dev, precision):
         lat.append((time.perf_counter() - t0) * 1e3)
     out["stream_16ch_hop_p50_ms"] = float(np.percentile(lat, 50))
     out["stream_16ch_hop_p99_ms"] = float(np.percentile(lat, 99))
-    out["note"] = ("the reference's own call sizes, outside the timed region and never `value`: numpy in -> numpy out per call at batch 32 / 128, "
+    out["note"] = ("the reference's own call sizes, outside the timed region and never `value`: numpy in -> numpy out per call at batch 32 / 128 "
+                   "(one synchronous call at a time), the same batches as a loop with two in flight (ecapa_encode_batches, what embed_segments calls), "
                    "and configs[3]'s 16-channel hop (2 s window every 250 ms) as one graph replay")
     return out
 
