@@ -66,7 +66,7 @@ def _power_spectrogram_f64(wavs: np.ndarray, n_fft: int, hop: int, window: np.nd
     x = np.asarray(wavs, dtype=np.float64)
     pad = n_fft // 2
     xp = np.pad(x, ((0, 0), (pad, pad)), mode="reflect" if pad_mode == "reflect" else "constant")
-    T = 1 + x.shape[1] // hop
+    T = 1 + (xp.shape[1] - n_fft) // hop          # torch.stft: = 1 + n // hop for an even n_fft, 1 + (n - 1) // hop for an odd one
     idx = np.arange(T)[:, None] * hop + np.arange(n_fft)[None, :]
     frames = xp[:, idx] * window[None, None, :]
     spec = np.fft.rfft(frames, n=n_fft, axis=-1)

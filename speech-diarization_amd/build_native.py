@@ -21,7 +21,7 @@ LIB_PATH = PKG_DIR / "libsd_hip.so"
 STAMP = PKG_DIR / "csrc" / ".build_stamp"
 OFFLOAD_ARCH = "gfx950"
 
-SOURCES = ["sd_api.hip", "sd_conv_gemm.hip", "sd_conv_gemm_f16.hip", "sd_res2net_f16.hip", "sd_fbank.hip", "sd_fbank_utt16.hip", "sd_pool.hip", "sd_scores.hip", "sd_asp_fused.hip", "sd_affinity.hip", "sd_ecapa.hip"]
+SOURCES = ["sd_api.hip", "sd_conv_gemm.hip", "sd_conv_gemm_f16.hip", "sd_res2net_f16.hip", "sd_fbank.hip", "sd_fbank_utt16.hip", "sd_fbank_generic.hip", "sd_pool.hip", "sd_scores.hip", "sd_asp_fused.hip", "sd_affinity.hip", "sd_ecapa.hip"]
 
 
 def _hipcc() -> str:

@@ -471,11 +471,20 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
                                                int pad_mode, int log_mode, float log_eps, float top_db) {
   auto fail = [](int code, const char* msg) -> sd_fbank_plan* { sd_set_error(code, "%s", msg); return nullptr; };
   if (!window || !mel_fb) return fail(SD_ERR_ARG, "sd_fbank_plan_create: null window/mel_fb");
-  if (n_fft != NFFT || hop != HOP)
-    return fail(SD_ERR_UNSUPPORTED, "sd_fbank_plan_create: only n_fft=400, hop=160 (25 ms / 10 ms at 16 kHz) is implemented");
-  if (n_mels < 1 || n_mels > MAX_MELS) return fail(SD_ERR_UNSUPPORTED, "sd_fbank_plan_create: n_mels must be in [1, 80]");
   if (pad_mode != SD_PAD_ZERO && pad_mode != SD_PAD_REFLECT) return fail(SD_ERR_ARG, "sd_fbank_plan_create: bad pad_mode");
   if (log_mode != SD_LOG_LN_EPS && log_mode != SD_LOG_DB_TOPDB) return fail(SD_ERR_ARG, "sd_fbank_plan_create: bad log_mode");
+  if (n_fft != NFFT || hop != HOP || n_mels > MAX_MELS) {
+    // any other framing (fbank_batch at sr != 16 kHz, [REF speech_encode.py:14-24]): the DFT and the mel product as implicit GEMMs on
+    // the exact-f32 conv operator (sd_fbank_generic.hip); any window, no symmetry needed
+    if (!sd_fbank_generic_geometry_ok(n_fft, hop, n_mels))
+      return fail(SD_ERR_UNSUPPORTED, "sd_fbank_plan_create: need 8 <= n_fft <= 8192, 1 <= hop <= n_fft, 1 <= n_mels <= 256");
+    sd_fbank_plan* plan = new sd_fbank_plan{};
+    plan->n_fft = n_fft; plan->hop = hop; plan->n_mels = n_mels; plan->pad_mode = pad_mode; plan->log_mode = log_mode;
+    plan->log_eps = log_eps; plan->top_db = top_db; plan->generic = true;
+    if (sd_fbank_generic_create_tables(plan, window, mel_fb) != SD_OK) { delete plan; return nullptr; }
+    return plan;
+  }
+  if (n_mels < 1) return fail(SD_ERR_UNSUPPORTED, "sd_fbank_plan_create: n_mels must be positive");
   for (int k = 1; k < NFFT / 2; ++k)
     if (window[k] != window[NFFT - k])
       return fail(SD_ERR_UNSUPPORTED, "sd_fbank_plan_create: window must be symmetric (w[k] == w[n_fft-k])");
@@ -524,7 +533,9 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
                 m16[o] = part == 0 ? w1 : bf16_bits(w - bf16_value(w1));
               }
   }
-  sd_fbank_plan* plan = new sd_fbank_plan{n_fft, hop, n_mels, pad_mode, log_mode, log_eps, top_db, nullptr, nullptr, nullptr};
+  sd_fbank_plan* plan = new sd_fbank_plan{};
+  plan->n_fft = n_fft; plan->hop = hop; plan->n_mels = n_mels; plan->pad_mode = pad_mode; plan->log_mode = log_mode;
+  plan->log_eps = log_eps; plan->top_db = top_db;
   hipError_t e1 = hipMalloc(&plan->basis16_dev, V2_BASIS_BYTES);
   hipError_t e2 = e1 == hipSuccess ? hipMalloc(&plan->melw16_dev, V2_MELW_BYTES) : e1;
   if (e1 == hipSuccess && e2 == hipSuccess) {
@@ -550,6 +561,7 @@ extern "C" sd_fbank_plan* sd_fbank_plan_create(const float* window, int n_fft, i
 
 extern "C" void sd_fbank_plan_destroy(sd_fbank_plan* plan) {
   if (!plan) return;
+  if (plan->generic) { sd_fbank_generic_destroy_tables(plan); delete plan; return; }
   (void)hipFree(plan->basis16_dev);
   (void)hipFree(plan->melw16_dev);
   sd_fbank_utt16_destroy_tables(plan);
@@ -558,10 +570,12 @@ extern "C" void sd_fbank_plan_destroy(sd_fbank_plan* plan) {
 
 extern "C" int sd_fbank_num_frames(const sd_fbank_plan* plan, int n) {
   if (!plan || n < 0) return sd_set_error(SD_ERR_ARG, "sd_fbank_num_frames: bad arguments");
+  if (plan->generic) return sd_fbank_generic_num_frames(plan, n);
   return 1 + n / plan->hop;
 }
 
-extern "C" size_t sd_fbank_workspace_bytes(const sd_fbank_plan*, int B, int) {
+extern "C" size_t sd_fbank_workspace_bytes(const sd_fbank_plan* plan, int B, int n) {
+  if (plan && plan->generic) return sd_fbank_generic_workspace_bytes(plan, B, n);
   return ((size_t)(B > 0 ? B : 0) * sizeof(int) + 255) & ~(size_t)255;
 }
 
@@ -592,9 +606,10 @@ static int fbank_launch(const sd_fbank_plan* plan, const float* wav_dev, long lo
   SD_CHECK_ARG(ld_out >= plan->n_mels, "sd_fbank_f32: ld_out=%d < n_mels=%d", ld_out, plan->n_mels);
   // torch.stft(center=True, pad_mode="reflect") rejects n <= n_fft/2; zero padding needs one sample
   if (plan->pad_mode == SD_PAD_REFLECT)
-    SD_CHECK_ARG(n > NFFT / 2, "sd_fbank_f32: reflect padding of %d needs more than %d samples (got %d)", NFFT / 2, NFFT / 2, n);
+    SD_CHECK_ARG(n > plan->n_fft / 2, "sd_fbank_f32: reflect padding of %d needs more than %d samples (got %d)", plan->n_fft / 2, plan->n_fft / 2, n);
   else
     SD_CHECK_ARG(n >= 1, "sd_fbank_f32: empty waveform");
+  if (plan->generic) return sd_fbank_generic_launch(plan, wav_dev, n_total, starts_dev, B, n, mean_norm, out_dev, ld_out, ws_dev, ws_bytes, stream);
   SD_CHECK_ARG(ws_dev != nullptr && ws_bytes >= sd_fbank_workspace_bytes(plan, B, n),
                "sd_fbank_f32: workspace too small (%zu < %zu)", ws_bytes, sd_fbank_workspace_bytes(plan, B, n));
   // utterances whose padded signal fits the CU's LDS: ONE launch, one workgroup per utterance (sd_fbank_utt16.hip)

@@ -312,7 +312,7 @@ def fbank_windows_device(signal: torch.Tensor, starts: torch.Tensor, n: int, pla
     signal = signal.contiguous().float()
     starts = starts.to(signal.device, dtype=torch.int64).contiguous()
     B = int(starts.numel())
-    T = FbankPlan.num_frames(n)
+    T = plan.frames(int(n))
     out = torch.empty((B, T, plan.n_mels), dtype=torch.float32, device=signal.device)
     if B == 0:
         return out
@@ -333,7 +333,7 @@ def fbank_device(wav: torch.Tensor, plan: FbankPlan, mean_norm: bool = True) -> 
     lib = N.load()
     wav = wav.contiguous().float()
     B, n = wav.shape
-    T = FbankPlan.num_frames(n)
+    T = plan.frames(n)
     out = torch.empty((B, T, plan.n_mels), dtype=torch.float32, device=wav.device)
     if B == 0:
         return out

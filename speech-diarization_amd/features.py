@@ -46,14 +46,15 @@ def periodic_window(kind: str, n: int = N_FFT) -> np.ndarray:
         raise ValueError(f"unknown window {kind!r}")
     w = w.astype(np.float32)
     # enforce exact symmetry w[k] == w[n-k] after rounding (the kernel folds the DFT on it)
-    w[n // 2 + 1:] = w[1:n // 2][::-1]
+    w[n // 2 + 1:] = w[1:(n + 1) // 2][::-1]
     return w
 
 
-def mel_filters_torchaudio(n_mels: int = 80, sr: int = 16000, f_min: float = 20.0, f_max: float | None = None) -> np.ndarray:
+def mel_filters_torchaudio(n_mels: int = 80, sr: int = 16000, f_min: float = 20.0, f_max: float | None = None,
+                           n_freq: int = N_FREQ) -> np.ndarray:
     """torchaudio.functional.melscale_fbanks(mel_scale="htk", norm=None) -> [n_freq, n_mels]."""
     f_max = sr / 2 - 100 if f_max is None else f_max
-    freqs = np.linspace(0.0, sr // 2, N_FREQ)
+    freqs = np.linspace(0.0, sr // 2, n_freq)
     pts = _mel_to_hz(np.linspace(_hz_to_mel(f_min), _hz_to_mel(f_max), n_mels + 2))
     diff = pts[1:] - pts[:-1]
     slopes = pts[None, :] - freqs[:, None]
@@ -95,16 +96,22 @@ class FbankPlan:
         if kind not in FRONT_ENDS:
             raise ValueError(f"unknown front end {kind!r}")
         win_length, hop = int(sr * 0.025), int(sr * 0.010)  # [REF speech_encode.py:14-15]
-        if (win_length, hop) != (N_FFT, HOP):
-            raise NotImplementedError(f"HIP fbank implements 16 kHz framing (n_fft=400, hop=160); sr={sr} gives {win_length}/{hop}")
+        if kind == "speechbrain" and (win_length, hop) != (N_FFT, HOP):
+            raise ValueError(f"the ECAPA encoder's own front end is 16 kHz (n_fft=400, hop=160); sr={sr} gives {win_length}/{hop}")
+        if win_length < 8 or hop < 1:
+            raise ValueError(f"sr={sr} gives a window of {win_length} samples and a hop of {hop}")
         fe = FRONT_ENDS[kind]
         self.kind, self.n_mels, self.sr = kind, n_mels, sr
-        self.window = periodic_window(fe.window)
-        self.mel = (mel_filters_torchaudio(n_mels, sr) if fe.filters == "torchaudio" else mel_filters_speechbrain(n_mels, sr))
+        self.n_fft, self.hop = win_length, hop
+        # 16 kHz: the split-f16 kernels (sd_fbank_utt16.hip / sd_fbank.hip); any other rate: DFT + mel product as exact-f32
+        # implicit GEMMs (sd_fbank_generic.hip), the library decides from (n_fft, hop)
+        self.window = periodic_window(fe.window, win_length)
+        n_freq = win_length // 2 + 1
+        self.mel = (mel_filters_torchaudio(n_mels, sr, n_freq=n_freq) if fe.filters == "torchaudio" else mel_filters_speechbrain(n_mels, sr))
         self._lib = N.load()
         win = np.ascontiguousarray(self.window)
         mel = np.ascontiguousarray(self.mel)
-        self._h = self._lib.sd_fbank_plan_create(win.ctypes.data_as(C.c_void_p), N_FFT, HOP, mel.ctypes.data_as(C.c_void_p), n_mels,
+        self._h = self._lib.sd_fbank_plan_create(win.ctypes.data_as(C.c_void_p), win_length, hop, mel.ctypes.data_as(C.c_void_p), n_mels,
                                                  fe.pad_mode, fe.log_mode, C.c_float(fe.log_eps), C.c_float(fe.top_db))
         if not self._h:
             raise N.SdError(f"sd_fbank_plan_create failed: {N.last_error()}")
@@ -115,7 +122,12 @@ class FbankPlan:
 
     @staticmethod
     def num_frames(n: int) -> int:
+        """Frames of an n-sample utterance at the 16 kHz framing (the encoder's front end)."""
         return 1 + n // HOP
+
+    def frames(self, n: int) -> int:
+        """Frames at THIS plan's framing: torch.stft(center=True) gives 1 + (n + 2 (n_fft // 2) - n_fft) // hop."""
+        return 1 + (n + 2 * (self.n_fft // 2) - self.n_fft) // self.hop
 
     def workspace_bytes(self, B: int, n: int) -> int:
         return int(self._lib.sd_fbank_workspace_bytes(self._h, B, n))

@@ -45,8 +45,10 @@ def test_host_side_argument_validation_without_a_gpu():
     lib = _native.load()
     win = np.ones(400, np.float32)
     mel = np.zeros((201, 80), np.float32)
-    h = lib.sd_fbank_plan_create(win.ctypes.data_as(C.c_void_p), 512, 160, mel.ctypes.data_as(C.c_void_p), 80, 0, 0, 1e-6, -1.0)
-    assert not h and "n_fft=400" in _native.last_error()
+    h = lib.sd_fbank_plan_create(win.ctypes.data_as(C.c_void_p), 4, 2, mel.ctypes.data_as(C.c_void_p), 80, 0, 0, 1e-6, -1.0)
+    assert not h and "8 <= n_fft" in _native.last_error()              # (any other framing is accepted: sd_fbank_generic.hip)
+    h = lib.sd_fbank_plan_create(win.ctypes.data_as(C.c_void_p), 400, 401, mel.ctypes.data_as(C.c_void_p), 80, 0, 0, 1e-6, -1.0)
+    assert not h and "hop <= n_fft" in _native.last_error()
     win[3] = 0.5                                       # breaks w[k] == w[400-k]
     h = lib.sd_fbank_plan_create(win.ctypes.data_as(C.c_void_p), 400, 160, mel.ctypes.data_as(C.c_void_p), 80, 0, 0, 1e-6, -1.0)
     assert not h and "symmetric" in _native.last_error()

@@ -317,3 +317,77 @@ def test_fbank_achieved_error_is_recorded(dev, capsys):
     with capsys.disabled():
         print(f"\nfbank max abs error vs float64: torchaudio (ln) {out['torchaudio']:.3e}, speechbrain (dB) {out['speechbrain']:.3e}")
     assert out["torchaudio"] < 2e-4 and out["speechbrain"] < 1e-3
+
+
+@pytest.mark.parametrize("sr,n,B", [(8000, 16000, 5), (22050, 44100, 3), (22050, 22000, 2), (44100, 30000, 2), (48000, 96000, 3), (48000, 700, 1)])
+def test_fbank_batch_at_other_sample_rates(dev, sr, n, B):
+    """`fbank_batch(wavs, sr)` for sr != 16 kHz [REF speech_encode.py:14-24]: win_length = n_fft = int(sr * 0.025), hop = int(sr * 0.010),
+    f_max = sr / 2 - 100 (200 / 80, 551 / 220 -- an odd n_fft --, 1102 / 441, 1200 / 480).  The generic path (sd_fbank_generic.hip: DFT and
+    mel product as exact-f32 implicit GEMMs) against the float64 oracle, with and without mean removal, 40 and 80 bins."""
+    from oracle import fbank_ref
+    from speech_diarization_amd import speech_encode, synth
+    wav = synth.synthetic_segments(11, B, n, std=0.2)
+    for n_mels, mean_nor in ((80, True), (40, False)):
+        got = speech_encode.fbank_batch(wav, sr=sr, n_mels=n_mels, mean_nor=mean_nor)
+        ref = fbank_ref.fbank_batch_ref(wav, sr=sr, n_mels=n_mels, mean_nor=mean_nor)
+        assert got.shape == ref.shape and got.dtype == np.float32
+        assert np.abs(got - ref).max() < 2e-4, (sr, n_mels, np.abs(got - ref).max())
+
+
+def test_generic_fbank_plan_modes_windows_and_nan(dev):
+    """The generic framing under the other front end's switches (zero padding, dB law, top_db floor) -- n_mels = 96 sends the 16 kHz framing
+    down the generic path too, where it must agree with the split-f16 kernels --, windows read in place from one signal, several workspace
+    chunks, and a NaN sample (NaN features for its utterance, neighbours bitwise untouched)."""
+    import ctypes as C
+    from oracle import fbank_ref
+    from speech_diarization_amd import _native as N, synth
+    from speech_diarization_amd.engine import fbank_device, fbank_windows_device
+    from speech_diarization_amd.features import FbankPlan, FRONT_ENDS, periodic_window
+    lib = N.load()
+
+    class Plan(FbankPlan):                         # a plan from explicit tables: (n_fft, hop) and the front end's switches
+        def __init__(self, n_fft, hop, mel, kind):
+            fe = FRONT_ENDS[kind]
+            self.kind, self.n_mels, self.sr, self.n_fft, self.hop = kind, mel.shape[1], 16000, n_fft, hop
+            self._lib = lib
+            win = np.ascontiguousarray(periodic_window(fe.window, n_fft))
+            mel = np.ascontiguousarray(mel, dtype=np.float32)
+            self._h = lib.sd_fbank_plan_create(win.ctypes.data_as(C.c_void_p), n_fft, hop, mel.ctypes.data_as(C.c_void_p), mel.shape[1],
+                                               fe.pad_mode, fe.log_mode, C.c_float(fe.log_eps), C.c_float(fe.top_db))
+            assert self._h, N.last_error()
+
+    wav = synth.synthetic_segments(4, 6, 16000, std=0.2)
+    x = torch.from_numpy(wav).to(dev)
+    # speechbrain's switches at 16 kHz with 96 bins (> 80: generic path) against the oracle's formulation
+    mel96 = fbank_ref.speechbrain_filterbank(201, 96, 16000)
+    got = fbank_device(x, Plan(400, 160, mel96, "speechbrain"), mean_norm=True).cpu().numpy()
+    power = fbank_ref._power_spectrogram_f64(wav, 400, 160, fbank_ref._window("hamming", 400), "constant")
+    db = 10.0 * np.log10(np.clip(power @ mel96, 1e-10, None))
+    db = np.maximum(db, db.max(axis=(1, 2), keepdims=True) - 80.0)
+    assert np.abs(got - (db - db.mean(axis=1, keepdims=True))).max() < 1e-3
+    # the same tables as the 80-bin product kernels: generic (as 96 bins, the extra 16 all-zero filters) == split-f16 kernels to their tolerance
+    mel80 = np.concatenate([fbank_ref.melscale_fbanks_htk(201, 20.0, 7900.0, 80, 16000), np.zeros((201, 16))], axis=1)
+    g96 = fbank_device(x, Plan(400, 160, mel80, "torchaudio"), mean_norm=False).cpu().numpy()
+    fast = fbank_device(x, FbankPlan("torchaudio"), mean_norm=False).cpu().numpy()
+    assert np.abs(g96[:, :, :80] - fast).max() < 2e-4 and np.allclose(g96[:, :, 80:], np.log(1e-6), atol=1e-6)
+    # windows of one signal, read in place (zeros where a window hangs over an end): bitwise the gathered rows
+    plan8 = FbankPlan("torchaudio", sr=8000)
+    sig = torch.from_numpy(synth.synthetic_segments(9, 1, 40000, std=0.2)[0]).to(dev)
+    starts = torch.tensor([0, 777, 39000, 20000, -300], dtype=torch.int64)
+    rows = torch.zeros((5, 4000), device=dev)
+    for i, s in enumerate(starts.tolist()):
+        lo, hi = max(s, 0), min(s + 4000, 40000)
+        rows[i, lo - s: hi - s] = sig[lo:hi]
+    assert torch.equal(fbank_windows_device(sig, starts, 4000, plan8), fbank_device(rows, plan8))
+    # more utterances than one workspace chunk holds (48 kHz, 2 s: ~2 MB per utterance, chunks of ~128): chunk boundaries change nothing
+    plan48 = FbankPlan("torchaudio", sr=48000)
+    big = torch.from_numpy(synth.synthetic_segments(12, 150, 48000, std=0.2)).to(dev)
+    assert torch.equal(fbank_device(big, plan48)[140:], fbank_device(big[140:], plan48))
+    # NaN sample
+    bad = wav.copy()
+    bad[2, 5000] = np.nan
+    for mean_norm in (False, True):
+        g = fbank_device(torch.from_numpy(bad).to(dev), plan8, mean_norm=mean_norm).cpu().numpy()
+        c = fbank_device(x, plan8, mean_norm=mean_norm).cpu().numpy()
+        assert np.isnan(g[2]).any() and (not mean_norm or np.isnan(g[2]).all())
+        assert np.array_equal(np.delete(g, 2, axis=0), np.delete(c, 2, axis=0))

@@ -5,6 +5,7 @@ see oracle/__init__.py): each restatement is cross-checked against an independen
 and against analytic known answers.  Cosine semantics are pinned live against scikit-learn.
 """
 import numpy as np
+import pytest
 import torch
 
 from oracle import ecapa_ref, fbank_ref, pipeline_ref
@@ -20,6 +21,21 @@ def test_fbank_framed_dft_agrees_with_torch_stft():
     c = fbank_ref.speechbrain_fbank_ref(wav)
     d = fbank_ref.speechbrain_fbank_torch(torch.from_numpy(wav)).numpy()
     assert np.abs(c - d).max() < 5e-4
+
+
+@pytest.mark.parametrize("sr,n", [(8000, 8000), (22050, 22000), (22050, 11025), (44100, 30000), (48000, 24000)])
+def test_fbank_oracle_at_other_sample_rates_agrees_with_torch_stft(sr, n):
+    """`fbank_batch(wavs, sr)` derives its framing from sr [REF speech_encode.py:14-24]: 200 / 80 at 8 kHz, 551 / 220 (an ODD n_fft:
+    torch.stft then gives 1 + (n - 1) // hop frames) at 22.05 kHz, 1102 / 441, 1200 / 480.  The float64 framed DFT against
+    torch.stft in f32, frame count included."""
+    wav = synth.synthetic_segments(6, 2, n)
+    a = fbank_ref.fbank_batch_ref(wav, sr=sr)
+    b = fbank_ref.fbank_batch_torch(torch.from_numpy(wav), sr=sr).numpy()
+    n_fft, hop = int(sr * 0.025), int(sr * 0.010)
+    assert a.shape == b.shape == (2, 1 + (n + 2 * (n_fft // 2) - n_fft) // hop, 80)
+    assert np.abs(a - b).max() < 2e-4
+    assert features.periodic_window("hann", n_fft).shape == (n_fft,)
+    assert np.abs(features.mel_filters_torchaudio(80, sr, n_freq=n_fft // 2 + 1) - fbank_ref.melscale_fbanks_htk(n_fft // 2 + 1, 20.0, sr / 2 - 100, 80, sr)).max() < 1e-6
 
 
 def test_fbank_known_answers():

@@ -61,10 +61,16 @@ int main(void) {
   for (int k = 0; k < 201; ++k) mel[k * 80 + (k * 80) / 201] = 1.0f;
   EXPECT(sd_fbank_plan_create(NULL, 400, 160, mel, 80, 0, 0, 1e-6f, -1.f) == NULL, "null window");
   EXPECT(sd_fbank_plan_create(win, 400, 160, NULL, 80, 0, 0, 1e-6f, -1.f) == NULL, "null mel");
-  EXPECT(sd_fbank_plan_create(win, 512, 160, mel, 80, 0, 0, 1e-6f, -1.f) == NULL, "n_fft");
-  EXPECT(sd_fbank_plan_create(win, 400, 100, mel, 80, 0, 0, 1e-6f, -1.f) == NULL, "hop");
+  EXPECT(sd_fbank_plan_create(win, 4, 2, mel, 80, 0, 0, 1e-6f, -1.f) == NULL, "n_fft too small");
+  EXPECT(sd_fbank_plan_create(win, 16384, 160, mel, 80, 0, 0, 1e-6f, -1.f) == NULL, "n_fft too large");
+  EXPECT(sd_fbank_plan_create(win, 400, 0, mel, 80, 0, 0, 1e-6f, -1.f) == NULL, "hop 0");
+  EXPECT(sd_fbank_plan_create(win, 400, 401, mel, 80, 0, 0, 1e-6f, -1.f) == NULL, "hop > n_fft");
   EXPECT(sd_fbank_plan_create(win, 400, 160, mel, 0, 0, 0, 1e-6f, -1.f) == NULL, "n_mels 0");
   EXPECT(sd_fbank_plan_create(win, 400, 160, mel, 4096, 0, 0, 1e-6f, -1.f) == NULL, "n_mels large");
+  {                                          /* the generic framing (any sr): host tables for 200 / 80 are built, then the device is needed */
+    sd_fbank_plan* g = sd_fbank_plan_create(win, 200, 80, mel, 40, 1, 0, 1e-6f, -1.f);
+    if (g) { EXPECT(sd_fbank_num_frames(g, 8000) == 101, "generic frames"); (void)sd_fbank_workspace_bytes(g, 7, 8000); sd_fbank_plan_destroy(g); }
+  }
   EXPECT(sd_fbank_plan_create(win, 400, 160, mel, 80, 7, 0, 1e-6f, -1.f) == NULL, "pad mode");
   EXPECT(sd_fbank_plan_create(win, 400, 160, mel, 80, 0, 7, 1e-6f, -1.f) == NULL, "log mode");
   win[3] += 0.25f;
