@@ -2,24 +2,23 @@
 // (win_length = n_fft = int(sr * 0.025), hop = int(sr * 0.010): 200 / 80 at 8 kHz, 551 / 220 at 22.05 kHz, 1200 / 480 at 48 kHz).
 //
 // The 16 kHz framing (400 / 160) has kernels of its own (sd_fbank_utt16.hip, sd_fbank.hip: factored / folded DFT on split f16).  Every
-// other framing takes this path, which is built from the library's exact-f32 operators instead of a kernel per (n_fft, hop):
+// other framing takes this path; speed is secondary here (the reference's pipeline resamples to 16 kHz before it embeds,
+// [REF anti_stick_diarize.py:29-41]), accuracy is not:
 //
-//   1. fbg_rows_kernel      the padded signal (center = True: n_fft / 2 samples of reflect or zero padding at both ends) laid out as rows of
-//                           `hop` samples, channel-last [B * R][hop_pad]: frame t is the n_fft samples that start at row t, i.e. rows
-//                           t .. t + taps - 1 with taps = ceil(n_fft / hop) (made odd).
-//   2. sd_conv1d_cl_f32     the windowed real DFT of every frame as ONE implicit GEMM over those rows on the f32 matrix cores: a `taps`-tap
-//                           convolution whose weights are window[p] * cos / sin(2 pi k p / n_fft) at p = tap * hop + column (zero past
-//                           n_fft), cout = [re bins | im bins].  Output row t + taps / 2 is frame t; the reflect rows of the operator's
-//                           "same" padding only reach rows outside [taps / 2, taps / 2 + T) and are never read.
-//   3. fbg_power_kernel     re^2 + im^2.
-//   4. sd_conv1d_cl_f32     the mel product [n_freq] -> [n_mels] as a pointwise conv (dense: any filter shapes).
-//   5. fbg_finalize_kernel  log law, utterance maximum / top_db floor, mean over T, the write of out[b][t][m]; one workgroup per utterance.
+//   1. fbg_pad_kernel       the padded signal of every utterance (center = True: n_fft / 2 samples of reflect or zero padding at both ends).
+//   2. fbg_dft_f64_kernel   the windowed real DFT of every frame as a tiled [frames x n_fft] . [n_fft x (re | im)] product in FLOAT64 (v_fma_f64,
+//                           64 x 64 tiles, 4 x 4 outputs per thread, operands through LDS), frames gathered from the padded signal in place;
+//                           a thread owns re and im of a bin, so |X|^2 is formed in float64 and stored once as f32.
+//                           (A first version ran this product on the exact-f32 conv operator: 2.2e-4 (ln) from the float64 oracle in bins
+//                           50 dB below the frame's level -- the f32 accumulator of a 400-term sum whose partial sums reach ~1 while the
+//                           result is ~1e-2 -- against 3e-5 for torch's f32 FFT.  In float64 the DFT adds nothing to the error budget.)
+//   3. sd_conv1d_cl_f32     the mel product [n_freq] -> [n_mels] as a pointwise conv on the f32 matrix cores (a sum of non-negative terms:
+//                           no cancellation; dense, any filter shapes).
+//   4. fbg_finalize_kernel  log law, utterance maximum / top_db floor, mean over T, the write of out[b][t][m]; one workgroup per utterance.
 //
-// f32 products with f32 accumulation throughout (v_mfma_f32_32x32x2_f32 / 16x16x4): the arithmetic of torch's own f32 STFT.  Speed is
-// secondary here (the reference's pipeline resamples to 16 kHz before it embeds, [REF anti_stick_diarize.py:29-41]): 1.2 x the DFT's
-// flops for the zero-padded taps, four passes over a [frames][n_fft]-sized intermediate.  Utterances are processed in chunks so that the
-// workspace stays below ~256 MB whatever B is.  A NaN sample propagates the way the reference's arithmetic does: its frames' bins are
-// NaN, so is the utterance maximum (all features NaN under the top_db floor) and the mean over T (all NaN with mean removal).
+// Utterances are processed in chunks so that the workspace stays below ~256 MB whatever B is.  A NaN sample propagates the way the
+// reference's arithmetic does: its frames' bins are NaN, so is the utterance maximum (all features NaN under the top_db floor) and the
+// mean over T (all NaN with mean removal).
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -31,49 +30,80 @@ namespace {
 constexpr int FBG_MAX_NFFT = 8192;
 constexpr size_t FBG_CHUNK_BYTES = (size_t)256 << 20;
 
-struct RowsArgs {
+struct PadArgs {
   const float* wav; const long long* starts; long long n_total;
-  float* xp; int B0, Bc, n, R, hop, hop_pad, pad, pad_mode;
+  float* xpad; int B0, Bc, n, Lp, pad, pad_mode;
 };
 
-// xp[(b, r)][c] = padded signal at s = r * hop + c - pad (c < hop), 0 for c >= hop and wherever s lies outside the padded extent
-__global__ void fbg_rows_kernel(RowsArgs p) {
-  const long long total = (long long)p.Bc * p.R * p.hop_pad;
+// xpad[b][i] = padded signal at s = i - pad, i < Lp = n + 2 pad
+__global__ void fbg_pad_kernel(PadArgs p) {
+  const long long total = (long long)p.Bc * p.Lp;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % p.hop_pad);
-    const long long row = e / p.hop_pad;
-    const int r = (int)(row % p.R), b = (int)(row / p.R);
-    float v = 0.f;
-    if (c < p.hop) {
-      long long s = (long long)r * p.hop + c - p.pad;
-      bool ok = s >= -(long long)p.pad && s < (long long)p.n + p.pad;
-      if (p.pad_mode == SD_PAD_REFLECT) {
-        s = s < 0 ? -s : s;
-        s = s >= p.n ? 2LL * (p.n - 1) - s : s;
-        ok = ok && s >= 0 && s < p.n;
-      } else {
-        ok = ok && s >= 0 && s < p.n;
-      }
-      if (ok) {
-        const long long start = p.starts ? p.starts[p.B0 + b] : (long long)(p.B0 + b) * p.n;
-        const long long gi = start + s;
-        if (gi >= 0 && gi < p.n_total) v = p.wav[gi];            // a window may hang over either end of the signal: zeros there
-      }
+    const int b = (int)(e / p.Lp);
+    long long s = e - (long long)b * p.Lp - p.pad;
+    if (p.pad_mode == SD_PAD_REFLECT) {
+      s = s < 0 ? -s : s;
+      s = s >= p.n ? 2LL * (p.n - 1) - s : s;
     }
-    p.xp[e] = v;
+    float v = 0.f;
+    if (s >= 0 && s < p.n) {
+      const long long start = p.starts ? p.starts[p.B0 + b] : (long long)(p.B0 + b) * p.n;
+      const long long gi = start + s;
+      if (gi >= 0 && gi < p.n_total) v = p.wav[gi];              // a window may hang over either end of the signal: zeros there
+    }
+    p.xpad[e] = v;
   }
 }
 
-// pw[m][f] = y[m][f]^2 + y[m][nfp + f]^2, f < nfp (columns past n_freq are zero in y, hence in pw)
-__global__ void fbg_power_kernel(const float* y, float* pw, long long rows, int nfp) {
-  const int q = nfp >> 2;
-  const long long total = rows * q;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const long long m = e / q;
-    const int f = (int)(e - m * q) * 4;
-    const f32x4 re = *reinterpret_cast<const f32x4*>(y + m * 2 * nfp + f);
-    const f32x4 im = *reinterpret_cast<const f32x4*>(y + m * 2 * nfp + nfp + f);
-    *reinterpret_cast<f32x4*>(pw + m * nfp + f) = re * re + im * im;
+struct DftArgs {
+  const float* xpad; int Lp; int hop; int T; long long M;         // frame m = (b, t): n_fft samples at xpad[b * Lp + t * hop]
+  const double* tw; int n_fft; int ncol;                          // tw [n_fft][ncol]: column 2 k = w[p] cos(2 pi k p / n_fft), 2 k + 1 = -w[p] sin
+  float* pw; int nfp;                                             // pw [M][nfp] = re^2 + im^2 (bins past n_freq: zero)
+};
+
+constexpr int DT = 64, DK = 16;
+
+__global__ __launch_bounds__(256) void fbg_dft_f64_kernel(DftArgs p) {
+  __shared__ double As[DK][DT + 1];
+  __shared__ double Bs[DK][DT];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const long long m0 = (long long)blockIdx.x * DT;
+  const int c0 = blockIdx.y * DT;
+  // the frame this thread stages (one of the tile's 64) and its 4 K positions; the table element it stages
+  const int sf = tid & 63, sk = tid >> 6;
+  const long long sm = m0 + sf;
+  const float* srow = nullptr;
+  if (sm < p.M) { const long long b = sm / p.T; srow = p.xpad + b * p.Lp + (sm - b * p.T) * (long long)p.hop; }
+  double acc[4][4] = {};
+  for (int k0 = 0; k0 < p.n_fft; k0 += DK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = sk * 4 + i, pos = k0 + kk;
+      As[kk][sf] = (srow && pos < p.n_fft) ? (double)srow[pos] : 0.0;
+      Bs[kk][sf] = pos < p.n_fft ? p.tw[(size_t)pos * p.ncol + c0 + sf] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < DK; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][4 * ty + i]; b[i] = Bs[kk][4 * tx + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  // columns 4 tx .. 4 tx + 3 of the tile = (re, im) of bins (c0 + 4 tx) / 2 and + 1
+  const int bin = (c0 >> 1) + 2 * tx;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long m = m0 + 4 * ty + i;
+    if (m >= p.M) continue;
+    float* q = p.pw + m * p.nfp + bin;
+    q[0] = (float)(acc[i][0] * acc[i][0] + acc[i][1] * acc[i][1]);
+    q[1] = (float)(acc[i][2] * acc[i][2] + acc[i][3] * acc[i][3]);
   }
 }
 
@@ -143,12 +173,14 @@ __global__ __launch_bounds__(FIN_THREADS) void fbg_finalize_kernel(FinArgs p) {
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-size_t per_utterance_bytes(const sd_fbank_plan* plan, int R) {
-  return (size_t)R * ((size_t)plan->g_hop_pad + 3 * (size_t)plan->g_nfp + (size_t)plan->g_nmp) * sizeof(float);
+size_t pad_len(const sd_fbank_plan* plan, int n) { return ((size_t)n + 2 * (size_t)(plan->n_fft / 2) + 3) & ~(size_t)3; }
+
+size_t per_utterance_bytes(const sd_fbank_plan* plan, int n, int T) {
+  return (pad_len(plan, n) + (size_t)T * ((size_t)plan->g_nfp + (size_t)plan->g_nmp)) * sizeof(float);
 }
 
-int chunk_utterances(const sd_fbank_plan* plan, int B, int R) {
-  const size_t per = per_utterance_bytes(plan, R);
+int chunk_utterances(const sd_fbank_plan* plan, int B, int n, int T) {
+  const size_t per = per_utterance_bytes(plan, n, T);
   size_t bc = FBG_CHUNK_BYTES / (per ? per : 1);
   if (bc < 1) bc = 1;
   return (size_t)B < bc ? B : (int)bc;
@@ -167,36 +199,28 @@ int sd_fbank_generic_num_frames(const sd_fbank_plan* plan, int n) {
 }
 
 int sd_fbank_generic_create_tables(sd_fbank_plan* plan, const float* window, const float* mel_fb) {
-  const int n_fft = plan->n_fft, hop = plan->hop, n_mels = plan->n_mels;
-  int taps = (n_fft + hop - 1) / hop;
-  if (!(taps & 1)) ++taps;                                     // the operator centres an odd number of taps
+  const int n_fft = plan->n_fft, n_mels = plan->n_mels;
   const int n_freq = n_fft / 2 + 1;
-  plan->g_taps = taps;
-  plan->g_hop_pad = round_up(hop, 32);
   plan->g_nfreq = n_freq;
-  plan->g_nfp = round_up(n_freq, 64);
+  plan->g_nfp = round_up(n_freq, 32);                          // 32 bins = one 64-column tile of the DFT kernel; the mel product's K step
   plan->g_nmp = round_up(n_mels, 4);
-  const int hp = plan->g_hop_pad, nfp = plan->g_nfp;
-  // DFT weights, packed as the conv operator wants them: [cout = 2 nfp][taps][cin_pad = hop_pad]
-  std::vector<float> wd((size_t)2 * nfp * taps * hp, 0.f);
-  for (int k = 0; k < n_freq; ++k)
-    for (int j = 0; j < taps; ++j)
-      for (int c = 0; c < hop; ++c) {
-        const int pos = j * hop + c;
-        if (pos >= n_fft) continue;
-        const long long ph = ((long long)k * pos) % n_fft;
-        const double ang = 2.0 * M_PI * (double)ph / (double)n_fft;
-        const double w = (double)window[pos];
-        wd[((size_t)k * taps + j) * hp + c] = (float)(w * std::cos(ang));
-        wd[((size_t)(nfp + k) * taps + j) * hp + c] = (float)(-w * std::sin(ang));
-      }
+  const int nfp = plan->g_nfp, ncol = 2 * nfp;
+  // twiddles in float64, [n_fft][2 nfp]: (re, im) columns of a bin side by side
+  std::vector<double> tw((size_t)n_fft * ncol, 0.0);
+  for (int pos = 0; pos < n_fft; ++pos)
+    for (int k = 0; k < n_freq; ++k) {
+      const long long ph = ((long long)k * pos) % n_fft;
+      const double ang = 2.0 * M_PI * (double)ph / (double)n_fft;
+      tw[(size_t)pos * ncol + 2 * k] = (double)window[pos] * std::cos(ang);
+      tw[(size_t)pos * ncol + 2 * k + 1] = -(double)window[pos] * std::sin(ang);
+    }
   // mel weights [cout = n_mels][1][cin_pad = nfp]
   std::vector<float> wm((size_t)n_mels * nfp, 0.f);
   for (int m = 0; m < n_mels; ++m)
     for (int f = 0; f < n_freq; ++f) wm[(size_t)m * nfp + f] = mel_fb[(size_t)f * n_mels + m];
-  hipError_t e = hipMalloc(&plan->g_wdft_dev, wd.size() * sizeof(float));
+  hipError_t e = hipMalloc(&plan->g_wdft_dev, tw.size() * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&plan->g_wmel_dev, wm.size() * sizeof(float));
-  if (e == hipSuccess) e = hipMemcpy(plan->g_wdft_dev, wd.data(), wd.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(plan->g_wdft_dev, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(plan->g_wmel_dev, wm.data(), wm.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     sd_fbank_generic_destroy_tables(plan);
@@ -214,48 +238,40 @@ void sd_fbank_generic_destroy_tables(sd_fbank_plan* plan) {
 size_t sd_fbank_generic_workspace_bytes(const sd_fbank_plan* plan, int B, int n) {
   if (B <= 0 || n < 0) return 256;
   const int T = sd_fbank_generic_num_frames(plan, n);
-  const int R = T + plan->g_taps - 1;
-  return ((size_t)chunk_utterances(plan, B, R) * per_utterance_bytes(plan, R) + 1023) & ~(size_t)255;
+  return ((size_t)chunk_utterances(plan, B, n, T) * per_utterance_bytes(plan, n, T) + 1023) & ~(size_t)255;
 }
 
 int sd_fbank_generic_launch(const sd_fbank_plan* plan, const float* wav_dev, long long n_total, const long long* starts_dev, int B, int n,
                             int mean_norm, float* out_dev, int ld_out, void* ws_dev, size_t ws_bytes, hipStream_t stream) {
   const int T = sd_fbank_generic_num_frames(plan, n);
   SD_CHECK_ARG(T >= 1, "sd_fbank_f32: %d samples give no frame at n_fft=%d", n, plan->n_fft);
-  const int taps = plan->g_taps, hp = plan->g_hop_pad, nfp = plan->g_nfp, nmp = plan->g_nmp;
-  const int R = T + taps - 1;
-  SD_CHECK_ARG((long long)R * B < (1LL << 31), "sd_fbank_f32: too many frame rows");
+  const int nfp = plan->g_nfp, nmp = plan->g_nmp;
+  SD_CHECK_ARG((long long)T * B < (1LL << 31), "sd_fbank_f32: too many frames");
   SD_CHECK_ARG(sd_aligned16(ws_dev) && ws_bytes >= sd_fbank_generic_workspace_bytes(plan, B, n), "sd_fbank_f32: workspace too small or misaligned");
-  const int Bc = chunk_utterances(plan, B, R);
-  float* xp = static_cast<float*>(ws_dev);
-  float* y = xp + (size_t)Bc * R * hp;
-  float* pw = y + (size_t)Bc * R * 2 * nfp;
-  float* mel = pw + (size_t)Bc * R * nfp;
+  const int Bc = chunk_utterances(plan, B, n, T);
+  const int Lp = (int)pad_len(plan, n);
+  float* xpad = static_cast<float*>(ws_dev);
+  float* pw = xpad + (size_t)Bc * Lp;
+  float* mel = pw + (size_t)Bc * T * nfp;
   const int use_floor = plan->log_mode == SD_LOG_DB_TOPDB && plan->top_db >= 0.f;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int nb = B - b0 < Bc ? B - b0 : Bc;
-    const long long rows = (long long)nb * R;
-    RowsArgs ra{wav_dev, starts_dev, n_total, xp, b0, nb, n, R, plan->hop, hp, plan->n_fft / 2, plan->pad_mode};
-    const long long tot = rows * hp;
-    unsigned grid = (unsigned)((tot + 255) / 256 < 65536 ? (tot + 255) / 256 : 65536);
-    hipLaunchKernelGGL(fbg_rows_kernel, dim3(grid), dim3(256), 0, stream, ra);
-    SD_CHECK_LAUNCH("fbg_rows_kernel");
+    const long long M = (long long)nb * T;
+    PadArgs pa{wav_dev, starts_dev, n_total, xpad, b0, nb, n, Lp, plan->n_fft / 2, plan->pad_mode};
+    const long long tot = (long long)nb * Lp;
+    const unsigned grid = (unsigned)((tot + 255) / 256 < 65536 ? (tot + 255) / 256 : 65536);
+    hipLaunchKernelGGL(fbg_pad_kernel, dim3(grid), dim3(256), 0, stream, pa);
+    SD_CHECK_LAUNCH("fbg_pad_kernel");
+    DftArgs da{xpad, Lp, plan->hop, T, M, static_cast<const double*>(plan->g_wdft_dev), plan->n_fft, 2 * nfp, pw, nfp};
+    hipLaunchKernelGGL(fbg_dft_f64_kernel, dim3((unsigned)((M + DT - 1) / DT), (unsigned)(2 * nfp / DT)), dim3(256), 0, stream, da);
+    SD_CHECK_LAUNCH("fbg_dft_f64_kernel");
     sd_conv_args a;
     std::memset(&a, 0, sizeof(a));
-    a.x = xp; a.lda = hp; a.w = plan->g_wdft_dev; a.w_dtype = SD_DT_F32; a.y = y; a.ldo = 2 * nfp;
-    a.M = (int)rows; a.T = R; a.cin = hp; a.cin_pad = hp; a.cout = 2 * nfp; a.taps = taps; a.dil = 1;
-    a.act = SD_ACT_NONE; a.act2 = SD_ACT_NONE;
-    if (int e = sd_conv1d_cl_f32(&a, stream)) return e;
-    const long long pt = rows * (nfp >> 2);
-    grid = (unsigned)((pt + 255) / 256 < 65536 ? (pt + 255) / 256 : 65536);
-    hipLaunchKernelGGL(fbg_power_kernel, dim3(grid), dim3(256), 0, stream, y, pw, rows, nfp);
-    SD_CHECK_LAUNCH("fbg_power_kernel");
-    std::memset(&a, 0, sizeof(a));
     a.x = pw; a.lda = nfp; a.w = plan->g_wmel_dev; a.w_dtype = SD_DT_F32; a.y = mel; a.ldo = nmp;
-    a.M = (int)rows; a.T = 1; a.cin = nfp; a.cin_pad = nfp; a.cout = plan->n_mels; a.taps = 1; a.dil = 1;
+    a.M = (int)M; a.T = 1; a.cin = nfp; a.cin_pad = nfp; a.cout = plan->n_mels; a.taps = 1; a.dil = 1;
     a.act = SD_ACT_NONE; a.act2 = SD_ACT_NONE;
     if (int e = sd_conv1d_cl_f32(&a, stream)) return e;
-    FinArgs fa{mel, nmp, R, taps / 2, out_dev, ld_out, b0, T, plan->n_mels, plan->log_mode, plan->log_eps, plan->top_db, use_floor, mean_norm};
+    FinArgs fa{mel, nmp, T, 0, out_dev, ld_out, b0, T, plan->n_mels, plan->log_mode, plan->log_eps, plan->top_db, use_floor, mean_norm};
     hipLaunchKernelGGL(fbg_finalize_kernel, dim3((unsigned)nb), dim3(FIN_THREADS), 0, stream, fa);
     SD_CHECK_LAUNCH("fbg_finalize_kernel");
   }

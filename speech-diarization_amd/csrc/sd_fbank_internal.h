@@ -9,10 +9,10 @@ struct sd_fbank_plan {
   void* basis16_dev;       // folded-DFT kernel: f16 [pass][k step][tile][Chi | Clo | Shi | Slo][64][8]
   void* melw16_dev;        // folded-DFT kernel: bf16 [bin tile][k half][mel tile][W1 | W2][64][8]
   void* utt16_tables_dev;  // factored one-launch kernel (sd_fbank_utt16.hip): all of its fragment tables, 1 KB each
-  // any other framing (sd_fbank_generic.hip): the DFT and the mel product as implicit GEMMs on the exact-f32 conv operator
+  // any other framing (sd_fbank_generic.hip): a float64 DFT kernel + the mel product on the exact-f32 conv operator
   bool generic;
-  int g_taps, g_hop_pad, g_nfreq, g_nfp, g_nmp;
-  void* g_wdft_dev;        // f32 [2 nfp][taps][hop_pad]: window[p] cos / -sin(2 pi k p / n_fft) at p = tap * hop + column
+  int g_nfreq, g_nfp, g_nmp;
+  void* g_wdft_dev;        // f64 [n_fft][2 nfp]: window[p] cos / -sin(2 pi k p / n_fft), (re, im) of a bin side by side
   void* g_wmel_dev;        // f32 [n_mels][1][nfp]
 };
 

@@ -103,8 +103,8 @@ class FbankPlan:
         fe = FRONT_ENDS[kind]
         self.kind, self.n_mels, self.sr = kind, n_mels, sr
         self.n_fft, self.hop = win_length, hop
-        # 16 kHz: the split-f16 kernels (sd_fbank_utt16.hip / sd_fbank.hip); any other rate: DFT + mel product as exact-f32
-        # implicit GEMMs (sd_fbank_generic.hip), the library decides from (n_fft, hop)
+        # 16 kHz: the split-f16 kernels (sd_fbank_utt16.hip / sd_fbank.hip); any other rate: a float64 DFT kernel + the mel product
+        # on the exact-f32 conv operator (sd_fbank_generic.hip); the library decides from (n_fft, hop)
         self.window = periodic_window(fe.window, win_length)
         n_freq = win_length // 2 + 1
         self.mel = (mel_filters_torchaudio(n_mels, sr, n_freq=n_freq) if fe.filters == "torchaudio" else mel_filters_speechbrain(n_mels, sr))

@@ -322,8 +322,8 @@ def test_fbank_achieved_error_is_recorded(dev, capsys):
 @pytest.mark.parametrize("sr,n,B", [(8000, 16000, 5), (22050, 44100, 3), (22050, 22000, 2), (44100, 30000, 2), (48000, 96000, 3), (48000, 700, 1)])
 def test_fbank_batch_at_other_sample_rates(dev, sr, n, B):
     """`fbank_batch(wavs, sr)` for sr != 16 kHz [REF speech_encode.py:14-24]: win_length = n_fft = int(sr * 0.025), hop = int(sr * 0.010),
-    f_max = sr / 2 - 100 (200 / 80, 551 / 220 -- an odd n_fft --, 1102 / 441, 1200 / 480).  The generic path (sd_fbank_generic.hip: DFT and
-    mel product as exact-f32 implicit GEMMs) against the float64 oracle, with and without mean removal, 40 and 80 bins."""
+    f_max = sr / 2 - 100 (200 / 80, 551 / 220 -- an odd n_fft --, 1102 / 441, 1200 / 480).  The generic path (sd_fbank_generic.hip: the DFT in
+    float64, the mel product on the exact-f32 conv operator) against the float64 oracle, with and without mean removal, 40 and 80 bins."""
     from oracle import fbank_ref
     from speech_diarization_amd import speech_encode, synth
     wav = synth.synthetic_segments(11, B, n, std=0.2)
@@ -331,7 +331,7 @@ def test_fbank_batch_at_other_sample_rates(dev, sr, n, B):
         got = speech_encode.fbank_batch(wav, sr=sr, n_mels=n_mels, mean_nor=mean_nor)
         ref = fbank_ref.fbank_batch_ref(wav, sr=sr, n_mels=n_mels, mean_nor=mean_nor)
         assert got.shape == ref.shape and got.dtype == np.float32
-        assert np.abs(got - ref).max() < 2e-4, (sr, n_mels, np.abs(got - ref).max())
+        assert np.abs(got - ref).max() < 5e-5, (sr, n_mels, np.abs(got - ref).max())
 
 
 def test_generic_fbank_plan_modes_windows_and_nan(dev):
@@ -364,12 +364,15 @@ def test_generic_fbank_plan_modes_windows_and_nan(dev):
     power = fbank_ref._power_spectrogram_f64(wav, 400, 160, fbank_ref._window("hamming", 400), "constant")
     db = 10.0 * np.log10(np.clip(power @ mel96, 1e-10, None))
     db = np.maximum(db, db.max(axis=(1, 2), keepdims=True) - 80.0)
-    assert np.abs(got - (db - db.mean(axis=1, keepdims=True))).max() < 1e-3
+    assert np.abs(got - (db - db.mean(axis=1, keepdims=True))).max() < 2e-4
     # the same tables as the 80-bin product kernels: generic (as 96 bins, the extra 16 all-zero filters) == split-f16 kernels to their tolerance
     mel80 = np.concatenate([fbank_ref.melscale_fbanks_htk(201, 20.0, 7900.0, 80, 16000), np.zeros((201, 16))], axis=1)
     g96 = fbank_device(x, Plan(400, 160, mel80, "torchaudio"), mean_norm=False).cpu().numpy()
     fast = fbank_device(x, FbankPlan("torchaudio"), mean_norm=False).cpu().numpy()
-    assert np.abs(g96[:, :, :80] - fast).max() < 2e-4 and np.allclose(g96[:, :, 80:], np.log(1e-6), atol=1e-6)
+    ref80 = fbank_ref.fbank_batch_ref(wav, mean_nor=False)
+    print(f"generic fbank (float64 DFT) vs float64: {np.abs(g96[:, :, :80] - ref80).max():.3e}; split-f16 kernels vs float64: {np.abs(fast - ref80).max():.3e}")
+    assert np.abs(g96[:, :, :80] - ref80).max() < 5e-5 and np.abs(fast - ref80).max() < 2e-4
+    assert np.allclose(g96[:, :, 80:], np.log(1e-6), atol=1e-6)
     # windows of one signal, read in place (zeros where a window hangs over an end): bitwise the gathered rows
     plan8 = FbankPlan("torchaudio", sr=8000)
     sig = torch.from_numpy(synth.synthetic_segments(9, 1, 40000, std=0.2)[0]).to(dev)
