@@ -128,3 +128,44 @@ def speechbrain_fbank_torch(wavs: torch.Tensor, sr: int = 16000, n_mels: int = 8
     if mean_norm:
         x_db = x_db - x_db.mean(1, keepdim=True)
     return x_db
+
+
+# ----------------------------------------------------------- error model of an f32-class DFT (tests/test_gpu_fbank_ecapa.py, tools/fbank_error_model.py)
+
+def log_mel_error_unit(wavs: np.ndarray, kind: str = "torchaudio"):
+    """What a log-mel value may differ by from this float64 restatement when the DFT is computed in f32-class arithmetic.
+
+    A frame's DFT comes out with an absolute error delta = k 2^-22 A_t in re and im, where A_t^2 = sum_p (w_p x_p)^2 is the frame's windowed
+    energy (the level the bins of a white frame sit at; rounding errors of a length-N transform scale with the LARGEST component, not with the
+    bin).  A mel value mel_m = sum_k fb_mk |X_k|^2 then errs by at most 2 delta sqrt(S_m mel_m) (S_m = sum_k fb_mk, Cauchy-Schwarz, delta^2
+    dropped), its logarithm by that over (mel_m + eps), i.e. by at most
+
+        k * unit(t, m),     unit = 2^-22 A_t sqrt(S_m / (mel_tm + eps))        (natural-log units),
+
+    plus a level-independent r0 for the mel product and the log.  Quiet bins of loud frames are where it shows: 2 k 2^-22 10^(DR / 20) for a
+    bin DR dB below the frame's level.  Measured (tools/fbank_error_model.py, 32 seeds x 5 input classes): torch.stft in f32 -- the
+    arithmetic class of the reference's own path -- needs k <= 5.5 at r0 = 3e-5; the HIP kernels k <= 8.9 (one launch) / 4.2 (folded).
+
+    -> (ref [B, T, n_mels]: the raw log-mel values (no mean removal; top_db floor applied for "speechbrain"),
+        unit [B, T, n_mels] in the units of ref (ln, or dB for "speechbrain"),
+        live [B, T, n_mels] bool: False where the top_db floor replaced the value (no DFT error left in it))."""
+    x = np.asarray(wavs, dtype=np.float64)
+    if kind == "torchaudio":
+        win, pad_mode, eps = _window("hann", 400), "reflect", 1e-6
+        fb = melscale_fbanks_htk(201, 20.0, 7900.0, 80, 16000)
+    else:
+        win, pad_mode, eps = _window("hamming", 400), "constant", 1e-10
+        fb = speechbrain_filterbank(201, 80, 16000)
+    mel = _power_spectrogram_f64(x, 400, 160, win, pad_mode) @ fb
+    xp = np.pad(x, ((0, 0), (200, 200)), mode="reflect" if pad_mode == "reflect" else "constant")
+    idx = np.arange(mel.shape[1])[:, None] * 160 + np.arange(400)[None, :]
+    amp = np.sqrt(((xp[:, idx] * win) ** 2).sum(-1))                     # A_t, [B, T]
+    s = fb.sum(0)
+    if kind == "torchaudio":
+        ref = np.log(mel + eps)
+        unit = 2.0 ** -22 * amp[:, :, None] * np.sqrt(s[None, None, :] / (mel + eps))
+        return ref, unit, np.ones(ref.shape, dtype=bool)
+    db = 10.0 * np.log10(np.clip(mel, eps, None))
+    floor = db.max(axis=(1, 2), keepdims=True) - 80.0
+    unit = (10.0 / np.log(10.0)) * 2.0 ** -22 * amp[:, :, None] * np.sqrt(s[None, None, :] / np.maximum(mel, eps))
+    return np.maximum(db, floor), unit, db > floor + 1e-3
