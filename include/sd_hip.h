@@ -224,6 +224,11 @@ int sd_split16_pack_f32(const float* x, int ldx, int col0, int M, int C, float m
 /* SD_TUNE_TILE_ROWS: tiles of 80 / 96 / 112 rows x 128 columns in sd_conv1d_cl_f32 (16-row MFMA granularity, for launches whose 128-row
  * tiles divide badly over the CUs): 0 = never, 80 / 96 / 112 = that height whenever the layer allows, negative = by the rule (the default). */
 #define SD_TUNE_TILE_ROWS 6
+/* SD_TUNE_T256_LOCKSTEP_TILES: launches of the 256x256 f16 / f32-split16x3 ring kernel (register epilogue, column tiles in fours) with at least
+ * `value` tiles run as 256 persistent workgroups with a static schedule -- per pass an XCD's 32 workgroups take one super-tile of 8 activation
+ * row panels x 4 weight panels and share them in its L2 -- instead of one workgroup per tile: 0 = always, a huge value = never, negative = the
+ * default (1024 tiles).  Same bits either way. */
+#define SD_TUNE_T256_LOCKSTEP_TILES 7
 int sd_set_tuning(int key, long value);
 /* floats needed for sd_conv_args.colstat */
 size_t sd_colstat_floats(int M, int cout);

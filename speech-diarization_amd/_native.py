@@ -24,6 +24,7 @@ SD_TUNE_F16_NARROW_TILES = 3
 SD_TUNE_S64_TILES = 4
 SD_TUNE_HALF_TILES = 5
 SD_TUNE_TILE_ROWS = 6
+SD_TUNE_T256_LOCKSTEP_TILES = 7
 SD_MAX_RES2 = 15
 SD_MAX_BLOCKS = 8
 SD_ABI_VERSION = 10

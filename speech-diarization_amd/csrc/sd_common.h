@@ -13,6 +13,7 @@ int sd_set_error(int code, const char* fmt, ...);
 // SD_TUNE_F16_NARROW_TILES (sd_set_tuning): C-wide f16 / split16 layers with at most this many 256x256 tiles take the 128x128 kernel
 #include <atomic>
 std::atomic<long>& sd_f16_narrow_tiles();
+std::atomic<long>& sd_t256_lockstep_tiles();     // SD_TUNE_T256_LOCKSTEP_TILES (negative: 4 x the CU count)
 // library-internal entry points
 int sd_conv1d_cl_f32_symmetric(const sd_conv_args* a, sd_stream_t stream);   // sd_conv_gemm.hip: x == w, upper triangle + mirror
 int sd_conv1d_cl_f32_rows(const sd_conv_args* a, sd_stream_t stream, int* stat_rows);   // sd_conv_gemm.hip: sd_conv1d_cl_f32 that may write colstat in units of *stat_rows rows

@@ -1080,6 +1080,10 @@ extern "C" int sd_set_tuning(int key, long value) {
     sd_f16_narrow_tiles().store(value < 0 ? 128L : value, std::memory_order_relaxed);
     return SD_OK;
   }
+  if (key == SD_TUNE_T256_LOCKSTEP_TILES) {
+    sd_t256_lockstep_tiles().store(value < 0 ? -1L : value, std::memory_order_relaxed);
+    return SD_OK;
+  }
   return sd_set_error(SD_ERR_ARG, "sd_set_tuning: unknown key %d", key);
 }
 

@@ -571,15 +571,59 @@ __device__ __forceinline__ void sd_direct_epilogue(const sd_conv_args& p, ACC (&
 // half-slice does not collide with the next step's first B read (Bhi).
 // (The N x N cosine affinity had a SYM form of this kernel in round 3: upper-triangle tiles + an LDS-transposed mirror; superseded by
 // sd_affinity.hip, whose 128 x 128 tiles leave two workgroups on a CU: 3.2 -> 2.3 ms for 50 k x 50 k.)
+// SUPER-TILE WALK (round 5; super_walk != 0, register epilogue only): 256 PERSISTENT workgroups, one per CU, with a static schedule.  In
+// every pass the 32 workgroups of an XCD take one super-tile of 8 activation row panels x 4 weight column panels (slot s: row s / 4, column
+// s % 4); super-tiles are enumerated column group fastest and an XCD's share of them is contiguous.  All tiles cost the same, so an XCD's
+// workgroups move through their passes in step and the 32 co-resident tiles stream the SAME 8 + 4 operand panels through the XCD's 4 MB L2:
+// (8 + 4) / 32 panel fetches per tile instead of 1 + 1 / n_tiles under the hardware's own dispatch (one workgroup per tile, column tiles of a
+// row panel side by side).  What was measured on the way (tools/ab_t256_walk.sh, 1 005 000 rows, rocprofv3 --pmc FETCH_SIZE):
+//   * the fabric traffic VERDICT r4 flagged (2.65 x algorithmic) is NOT activations re-fetched by column tiles that miss each other in L2: the
+//     same 1-D tile order as a persistent lock-step schedule (every panel's column tiles start together) fetched the same bytes (81.1 vs
+//     82.2 M KiB) in the same time.  It is the WEIGHTS: 3072 x 3072 f16 = 18.9 MB do not fit the 4 MB L2, every row panel streams them again
+//     from the Infinity Cache (3926 panels x 18.9 MB = 74 GB worst case, 53 GB measured); at 1024 x 1024 (2 MB of weights) the traffic is
+//     1.55 x algorithmic;
+//   * the transposed 1-D walk (consecutive workgroups share a weight panel) trades that for activations streamed 12 times from HBM: 76 GB,
+//     +11 % time;
+//   * this 2-D walk halves the fetched bytes of the two shapes together (92.6 -> 45.9 M KiB) and runs 3072 x 3072 2.5 % faster (16.03 ->
+//     15.63 ms, 1184 -> 1214 TFLOP/s, both rounds); 1024 x 1024 is unchanged (2.05 ms).  The chip is power-limited in this kernel: the
+//     bytes that no longer cross the fabric come back as clock.
 template <typename TO, bool DIRECT, bool SPLIT = false>
-__global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec) {
+__global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_conv_args p, const int vec, const int super_walk) {
   constexpr int TBK = 64;
   constexpr int TROW = 128;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 #ifdef SD_STAMP
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), r_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int tid = threadIdx.x;
+  // Only the pass counter lives across a tile: the schedule and every lane constant of the body (staging roles, fragment offsets, row
+  // pointers) are recomputed per tile from an opaque copy of the thread id, so that nothing else occupies a register through the epilogue.
+  // (The LDS-staged epilogues keep the kernel arguments live in ~100 more SGPRs than there are: their walk is one pass, known at compile time.)
+  for (int pass = 0; DIRECT || pass < 1; ++pass) {
+  int tile_m, tile_n;
+  const int n_tiles = (p.cout + TBN - 1) / TBN;
+  if (super_walk) {
+    const int m_tiles = (p.M + TBM - 1) / TBM;
+    const int n_cg = n_tiles >> 2, n_rg = (m_tiles + 7) >> 3;
+    const int nst = n_cg * n_rg, b = blockIdx.x;
+    const int q = nst >> 3, r = nst & 7, xcd = b & 7, slot = b >> 3;
+    const int s_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int s_cnt = q + (xcd < r ? 1 : 0);
+    if (pass >= s_cnt) break;
+    const int st = s_lo + pass;
+    tile_m = 8 * (st / n_cg) + (slot >> 2);
+    tile_n = 4 * (st % n_cg) + (slot & 3);
+    if (tile_m >= m_tiles) continue;              // a ragged last row group: this slot idles for the pass (a pass has no barrier between workgroups)
+  } else {
+    // the hardware's dispatch, one workgroup per tile: XCD x (= blockIdx % 8) owns a contiguous range of the tile list
+    if (pass > 0) break;
+    const int nwg = (int)gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    tile_n = wg % n_tiles;
+    tile_m = wg / n_tiles;
+  }
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));           // opaque per pass: the lane constants below are not hoisted out of the walk
   const int lane = tid & 63;
 #ifdef SD_T256_UNIFORM_WID
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform for the compiler: LDS piece addresses (M0) on the scalar unit
@@ -588,15 +632,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
 #endif
   const int wm = wid >> 2, wn = wid & 3;
 
-  const int n_tiles = (p.cout + TBN - 1) / TBN;
-  int wg;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
-  const int tile_n = wg % n_tiles;
-  const int tile_m = wg / n_tiles;
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
   // staging role: within its group of 256 threads, thread (r0 = lt / 8, ps = lt % 8) fills physical 16-byte slot ps of rows
@@ -808,6 +843,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
       __syncthreads();
     }
 }
+  // the next tile's first DMA pieces land in stages 0 / 1: not before every wave has read its last fragments of this tile
+  if (super_walk) __syncthreads();
+#ifndef SD_STAMP
+  }   // tile walk
+#endif
 #ifdef SD_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
@@ -818,6 +858,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_f16_t256_kernel(const sd_con
     sd_stamp_buf[blockIdx.x * 8 + 3] = t_exit - t_entry;
     sd_stamp_buf[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime() - r_entry;
   }
+  }   // tile walk (stamp builds: the stamps are those of the workgroup's last tile)
 #endif
 }
 
@@ -1040,10 +1081,18 @@ int launch_t256(const sd_conv_args* a, int vec, hipStream_t stream) {
   const long tiles_n = (a->cout + TBN - 1) / TBN;
   auto kern = conv_gemm_f16_t256_kernel<TO, DIRECT, SPLIT>;
   SD_CHECK_HIP(sd_func_max_lds(reinterpret_cast<const void*>(kern), R3_LDS_BYTES));
+  // the super-tile walk (256 persistent workgroups, 8 x 4 tiles per XCD and pass) when the tile list is several rounds long, the chip has 8 x 32
+  // CUs and the column tiles come in fours (sd_set_tuning(SD_TUNE_T256_LOCKSTEP_TILES): from how many tiles; default 4 x the CU count)
+  static const int n_cu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; return n; }();
+  const long total = tiles_m * tiles_n;
+  long from = sd_t256_lockstep_tiles().load(std::memory_order_relaxed);
+  if (from < 0) from = 4L * 256;
+  const bool super = DIRECT && n_cu == 256 && tiles_n % 4 == 0 && total < (1L << 30) && total >= from;
   {
     // work = the algorithmic (f32-equivalent) flops: a split row carries cin / 2 values
     SdProfScope prof(SD_PROF_CONV_WIDE, stream, (SPLIT ? 1.0 : 2.0) * (double)a->M * (double)a->cout * (double)a->taps * (double)a->cin);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), R3_LDS_BYTES, stream, *a, vec);
+    if (super) hipLaunchKernelGGL(kern, dim3(256), dim3(512), R3_LDS_BYTES, stream, *a, vec, 1);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), R3_LDS_BYTES, stream, *a, vec, 0);
   }
   SD_CHECK_LAUNCH("conv_gemm_f16_t256_kernel");
   return SD_OK;
@@ -1072,6 +1121,11 @@ extern "C" int sd_debug_read_stamps(unsigned long long* out, int n) {
   return SD_OK;
 }
 #endif
+
+std::atomic<long>& sd_t256_lockstep_tiles() {
+  static std::atomic<long> v{-1L};
+  return v;
+}
 
 std::atomic<long>& sd_f16_narrow_tiles() {
   static std::atomic<long> v{128L};

@@ -426,3 +426,36 @@ def test_identical_clusters_at_full_geometry(dev):
         assert np.array_equal(lab[0], labels[0][0]) and np.array_equal(lab[1], labels[0][1])
     assert len(set(labels[0][0].tolist())) == 3
     assert _cos_dist(embs[0], embs[2]).max() < 1e-3 and _cos_dist(embs[1], embs[2]).max() < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["f16", "split16"])
+def test_t256_lockstep_walk_gives_the_bits_of_the_hardware_dispatch(dev, mode):
+    """Round 5: the 256x256 ring kernel's persistent lock-step walk (one workgroup per CU, XCD-contiguous static schedule;
+    sd_set_tuning(SD_TUNE_T256_LOCKSTEP_TILES)) computes every tile exactly as the one-workgroup-per-tile launch does: bitwise equal outputs,
+    also with a ragged last row tile, a tile count that is no multiple of 8, fewer tiles than CUs and several passes per workgroup."""
+    from speech_diarization_amd import _native, ops
+    lib = _native.load()
+    g = torch.Generator().manual_seed(3)
+    T = 201
+    try:
+        for B, cin, cout in ((3, 1024, 1024), (37, 1024, 1024), (350, 1024, 1024), (130, 3072, 3072)):
+            M = B * T
+            bias, scale, shift = torch.randn(cout, generator=g).to(dev), (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+            w = torch.randn(cout, cin, 1, generator=g) / cin ** 0.5
+            outs = []
+            for thr in (1 << 40, 0):
+                _native.check(lib.sd_set_tuning(_native.SD_TUNE_T256_LOCKSTEP_TILES, thr), "sd_set_tuning")
+                if mode == "f16":
+                    x = (torch.randn(M, cin, generator=g) * 0.5).half().to(dev) if not outs else x
+                    wp = ops.pack_weight(w, dev, torch.float16)
+                    y = torch.empty(M, cout, device=dev, dtype=torch.float16)
+                    ops.conv1d_cl(x, wp, T, cin=cin, bias=bias, act="relu", scale=scale, shift=shift, out=y)
+                else:
+                    x = torch.randn(M, cin, generator=g).to(dev) if not outs else x
+                    ws, s = ops.pack_weight_split16(w, dev)
+                    y = ops.conv1d_cl_split16(x, ws, s, T, cin=cin, bias=bias, act="relu", scale=scale, shift=shift)
+                outs.append(y)
+            assert torch.equal(outs[0], outs[1]), (mode, B, cin, cout)
+            assert bool(torch.isfinite(outs[1].float()).all())
+    finally:
+        _native.check(lib.sd_set_tuning(_native.SD_TUNE_T256_LOCKSTEP_TILES, -1), "sd_set_tuning")

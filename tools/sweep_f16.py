@@ -16,9 +16,13 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--colstat", action="store_true")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS check: same cycles, less switching energy)")
+    ap.add_argument("--lockstep", type=int, default=-1, help="SD_TUNE_T256_LOCKSTEP_TILES: 0 = always the persistent lock-step walk, 1 = never (a huge threshold), -1 = the default rule")
     ap.add_argument("shapes", nargs="+")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if a.lockstep >= 0:
+        from speech_diarization_amd import _native
+        _native.check(_native.load().sd_set_tuning(_native.SD_TUNE_T256_LOCKSTEP_TILES, 0 if a.lockstep == 0 else 1 << 40), "sd_set_tuning")
     M = a.B * a.T
     cases = []
     for s in a.shapes:
