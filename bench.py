@@ -126,6 +126,20 @@ def load_traffic():
     return load_profile_json("traffic.json")
 
 
+def counters_match_sources():
+    """The PMC counters on the line are file reads (separate rocprofv3 --pmc passes): do they come from the kernels in the tree?  Each file
+    records the fingerprint of csrc/ + include/ it was measured on (tools/import_profiles.py); compared with today's sources."""
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("sd_check_profiles", os.path.join(ROOT, "tools", "check_profiles_fresh.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        st = mod.status()
+        return {"all": all(v == "ok" for v in st.values()), "files": st}
+    except Exception as e:      # the counters are context, never worth failing a bench run for
+        return {"all": False, "error": repr(e)}
+
+
 def reference_batches(state_dict, dev, precision):
     """The hot path the way the reference itself calls it (never `value`): `ecapa_encode_batch(numpy [B, 32000]) -> numpy` at its batches of 32
     [REF anti_stick_diarize.py:134] and 128 [REF anti_stick_diarize.py:398] (pageable host memory in, H2D, fbank + ECAPA, D2H, a synchronisation
@@ -493,6 +507,7 @@ def main():
                 "flops_per_launch": conv_flops / max(conv_n, 1),
                 "share_of_step_time": conv_ms * 1e-3 / dt,
             },
+            "counters_match_sources": counters_match_sources(),
             "roofline_other_convs": {
                 "kernel": other_kernel + (" (+ res2net_chain_f16_kernel)" if half else ""), "bound": "mfma", "achieved": narrow_tflops,
                 "peak": mfma_peak, "unit": "TFLOP/s", "frac": narrow_tflops / mfma_peak, "launches": narrow_n,

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("csv")
     ap.add_argument("--out", default="profiles/mfma_util.json")
     ap.add_argument("--note", default="")
+    ap.add_argument("--fingerprint", default="", help="source fingerprint of csrc/ + include/ the profiled library was built from (tools/check_profiles_fresh.py)")
     a = ap.parse_args()
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(a.csv)):
@@ -33,6 +34,8 @@ def main():
         busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         if act > 0 and busy > 0:
             out[k] = {"mfma_util": busy / (act * 1024.0), "mfma_busy_cycles": busy, "active_cycles": act}
+    if a.fingerprint:
+        out["_source_fingerprint"] = a.fingerprint
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

@@ -9,6 +9,13 @@ common="--no-f16-extra --no-split-extra --no-cpu-baseline"
 precisions=${PRECISIONS:-"f32 f16 f32s"}          # PRECISIONS="f32s" bash tools/refresh_profiles.sh: only that engine
 rm -rf $out
 mkdir -p $out
+# the fingerprint of the kernel sources THIS box runs (build_native.py's stamp): tools/import_profiles.py records it in the JSON files, and
+# tools/check_profiles_fresh.py / bench.py compare it with the tree, so the bench line can never quote counters of an older kernel unnoticed
+python3 - > $out/source_fingerprint.txt <<'PY'
+import importlib.util
+spec = importlib.util.spec_from_file_location("b", "speech-diarization_amd/build_native.py"); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+print(m._fingerprint())
+PY
 for p in $precisions; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$p -- python3 bench.py --precision $p --steps 3 --warmup 1 $common > $out/$p.log 2>&1
   echo "$p stats done"

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("write_csv")
     ap.add_argument("--out", default="profiles/traffic.json")
     ap.add_argument("--note", default="")
+    ap.add_argument("--fingerprint", default="", help="source fingerprint of csrc/ + include/ the profiled library was built from (tools/check_profiles_fresh.py)")
     a = ap.parse_args()
     f_tot, f_cnt = per_kernel(a.fetch_csv, "FETCH_SIZE")
     w_tot, w_cnt = per_kernel(a.write_csv, "WRITE_SIZE")
@@ -51,6 +52,8 @@ def main():
         detail[k] = {"launches": n, "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
                      "fetch_size_raw_kib_total": f_tot.get(k, 0.0), "write_size_raw_kib_total": w_tot.get(k, 0.0)}
     out["_detail"] = detail
+    if a.fingerprint:
+        out["_source_fingerprint"] = a.fingerprint
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)
     for k, v in detail.items():
