@@ -152,6 +152,9 @@ def reference_batches(state_dict, dev, precision):
     speech_encode.set_precision(precision)
     for batch, warm, reps in ((32, 80, 80), (128, 30, 30)):
         wavs = synth.synthetic_segments(5, batch, 32000)
+        # (host-side generation first: the card's clocks take ~100 calls to settle after an idle stretch, so nothing slow may sit between
+        # a warm-up and its measurement)
+        many = [synth.synthetic_segments(50 + i, batch, 32000) for i in range(32 if batch == 32 else 12)]
         for _ in range(warm):
             speech_encode.ecapa_encode_batch(wavs)
         lat = []
@@ -164,11 +167,14 @@ def reference_batches(state_dict, dev, precision):
         out[f"numpy_batch{batch}_ms_per_call"] = med * 1e3
         # the same batches as the reference's callers issue them -- a LOOP over independent batches [REF anti_stick_diarize.py:150-171] -- through
         # `ecapa_encode_batches` (what `embed_segments` calls): two batches in flight on two streams, results bitwise those of the calls above
-        many = [synth.synthetic_segments(50 + i, batch, 32000) for i in range(24 if batch == 32 else 12)]
-        speech_encode.ecapa_encode_batches(many)
-        t0 = time.perf_counter()
-        got = speech_encode.ecapa_encode_batches(many)
-        dt = time.perf_counter() - t0
+        for _ in range(3):
+            got = speech_encode.ecapa_encode_batches(many)
+        passes = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            got = speech_encode.ecapa_encode_batches(many)
+            passes.append(time.perf_counter() - t0)
+        dt = float(np.median(passes))
         out[f"loop_batch{batch}_two_in_flight_segments_per_s"] = batch * len(many) / dt
         out[f"loop_batch{batch}_two_in_flight_ms_per_batch"] = dt / len(many) * 1e3
         out[f"loop_batch{batch}_bitwise_equal_to_single_calls"] = bool(all(np.array_equal(g, speech_encode.ecapa_encode_batch(w)) for g, w in zip(got[:3], many[:3])))
