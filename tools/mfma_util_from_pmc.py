@@ -25,7 +25,8 @@ def main():
     a = ap.parse_args()
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(a.csv)):
-        m = re.search(r"([A-Za-z_0-9]+_kernel)\b", r["Kernel_Name"]) or re.search(r"\d([a-z][a-z0-9_]*?_kernel)", r["Kernel_Name"])   # demangled, else Itanium-mangled
+        kn = r["Kernel_Name"]            # Itanium-mangled names first: the demangled pattern would swallow the _ZN12_GLOBAL__N_1.. prefix
+        m = re.search(r"\d([a-z][a-z0-9_]*?_kernel)", kn) if kn.startswith("_Z") else re.search(r"([A-Za-z_0-9]+_kernel)\b", kn)
         if m:
             acc[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"])
     out = {"_note": a.note or "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs), summed over all launches of the kernel"}

@@ -23,7 +23,8 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"([A-Za-z_0-9]+_kernel(?:<(?:true|false)>)?)", r["Kernel_Name"]) or re.search(r"\d([a-z][a-z0-9_]*?_kernel)", r["Kernel_Name"])   # demangled, else Itanium-mangled
+        kn = r["Kernel_Name"]            # Itanium-mangled names (_ZN12_GLOBAL__N_125conv_..._kernelI...) first: the demangled pattern would swallow the prefix
+        m = re.search(r"\d([a-z][a-z0-9_]*?_kernel)", kn) if kn.startswith("_Z") else re.search(r"([A-Za-z_0-9]+_kernel(?:<(?:true|false)>)?)", kn)
         if not m:
             continue                        # torch / runtime helper kernels
         name = m.group(1)
@@ -51,6 +52,10 @@ def main():
         out[k] = fetch + write
         detail[k] = {"launches": n, "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
                      "fetch_size_raw_kib_total": f_tot.get(k, 0.0), "write_size_raw_kib_total": w_tot.get(k, 0.0)}
+    for k in list(detail):               # also under the bare name when only one instantiation of a kernel ran (bench.py looks kernels up by bare name)
+        bare = k.split("<")[0]
+        if bare != k and sum(1 for q in detail if q.split("<")[0] == bare) == 1:
+            out[bare] = out[k]
     out["_detail"] = detail
     if a.fingerprint:
         out["_source_fingerprint"] = a.fingerprint
