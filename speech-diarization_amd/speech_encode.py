@@ -199,23 +199,31 @@ class HipEcapaEncoder:
                 out[i] = lane.host_out[:rows].numpy().copy()
                 lane.pending = None
 
-        for i, b in enumerate(batches):
-            lane = use[i % len(use)]
-            harvest(lane)                                   # its previous batch: frees the lane's staging buffers
-            rows, n = b.shape
-            if rows == 0:
-                out[i] = np.empty((0, self.embedding_dim), dtype=np.float32)
-                continue
-            h_in, h_out = lane.staging(rows, n, self.embedding_dim)
-            h_in.numpy()[...] = b
-            with torch.cuda.stream(lane.stream):
-                x = h_in.to(self.device, non_blocking=True)
-                emb = lane.engine.embed(x)
-                h_out.copy_(emb, non_blocking=True)
-                lane.done.record(lane.stream)
-            lane.pending = (i, rows)
-        for lane in use:
-            harvest(lane)
+        try:
+            for i, b in enumerate(batches):
+                lane = use[i % len(use)]
+                harvest(lane)                                   # its previous batch: frees the lane's staging buffers
+                rows, n = b.shape
+                if rows == 0:
+                    out[i] = np.empty((0, self.embedding_dim), dtype=np.float32)
+                    continue
+                h_in, h_out = lane.staging(rows, n, self.embedding_dim)
+                h_in.numpy()[...] = b
+                with torch.cuda.stream(lane.stream):
+                    x = h_in.to(self.device, non_blocking=True)
+                    emb = lane.engine.embed(x)
+                    h_out.copy_(emb, non_blocking=True)
+                    lane.done.record(lane.stream)
+                lane.pending = (i, rows)
+            for lane in use:
+                harvest(lane)
+        except BaseException:
+            # a batch was refused (too short, wrong shape, ...) or the caller interrupted: let what is in flight finish and forget it, so
+            # that the lanes' staging buffers are free and nothing of this call is harvested into the next one
+            for lane in use:
+                lane.stream.synchronize()
+                lane.pending = None
+            raise
         return out
 
     @torch.inference_mode()

@@ -192,6 +192,10 @@ def test_batches_in_flight_give_the_bits_of_one_call_at_a_time(small_encoder):
     assert all(np.array_equal(a, b) for a, b in zip(batches, keep))
     assert speech_encode.ecapa_encode_batches([]) == []
     assert np.array_equal(enc.encode_batches(batches[:1], lanes=2)[0], want[0])             # fewer batches than lanes
+    with pytest.raises(ValueError, match="too short"):                                       # a refused batch in the middle: the error of the single call,
+        speech_encode.ecapa_encode_batches([batches[0], np.zeros((2, 300), np.float32), batches[2]])
+    again = speech_encode.ecapa_encode_batches(batches[:3])                                  # and the lanes are clean afterwards
+    assert all(np.array_equal(a, w) for a, w in zip(again, want[:3]))
     conv = synth.synthetic_conversation(40.0, 2, seed=5)
     y = conv.wav.astype(np.float32)
     segs = [asd.Segment(0.3 * k, 0.3 * k + 0.2 + 0.05 * (k % 17)) for k in range(100)]      # 100 segments -> 4 batches of ragged lengths
