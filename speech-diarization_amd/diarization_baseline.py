@@ -269,9 +269,9 @@ def plan_speaker_tracks(segments, max_segment_s: float, max_gap_s: float):
 
 def extract_speaker_stems(audio: str | Path | dict, segments: list[tuple[float, float, str | int]], root: str | Path,
                           max_segment_s: float, max_gap_s: float, fade_ms: float, min_stem_s: float) -> dict[str | int, list[str]]:
-    """One or more stems per speaker under `<root>/<speaker>/<stem>-NNN.wav` (16-bit), pieces faded
-    in/out linearly, silences between pieces capped at `max_gap_s`, stems shorter than
-    `min_stem_s` skipped.  (The reference writes FLAC through torchaudio; no FLAC codec here.)"""
+    """One or more stems per speaker under `<root>/<speaker>/<stem>-NNN.flac` (16-bit FLAC, as the reference writes them
+    [REF diarization_baseline.py:95-103]; `flac.py`), pieces faded in/out linearly, silences between pieces capped at `max_gap_s`,
+    stems shorter than `min_stem_s` skipped."""
     if isinstance(audio, (str, Path)):
         y, sr = audio_io.read_audio(audio, sr=16000, mono=False)
         stem_name = Path(audio).stem
@@ -301,9 +301,9 @@ def extract_speaker_stems(audio: str | Path | dict, segments: list[tuple[float, 
             wave = np.concatenate(chunks, axis=1)
             if wave.shape[1] / sr < min_stem_s:
                 continue
-            path = root / f"{spk}/{stem_name}-{len(out[spk]):03d}.wav"
+            path = root / f"{spk}/{stem_name}-{len(out[spk]):03d}.flac"
             path.parent.mkdir(parents=True, exist_ok=True)
-            audio_io.write_wav16(path, wave, sr)
+            audio_io.write_flac16(path, wave, sr)
             out[spk].append(str(path.absolute()))
     return dict(out)
 

@@ -58,7 +58,7 @@ def test_diarizer_end_to_end_writes_stems(conversation, tmp_path):
     assert len({k for _, _, k in segments}) == 2
     assert set(info) == {k for _, _, k in segments}
     for spk, files in info.items():
-        assert files and all(f.endswith(".wav") and f"/{spk}/meeting-" in f for f in files)
+        assert files and all(f.endswith(".flac") and f"/{spk}/meeting-" in f for f in files)
         for f in files:
             y, sr = audio_io.read_audio(f, 16000, mono=True)
             assert 3.0 <= len(y) / sr <= hp.max_segment_s + 1e-6
